@@ -1,0 +1,171 @@
+/*
+ * C ABI of libv2vae_hip.so: the V2VAE training hot path on MI355X (gfx950).
+ *
+ * Every entry point takes borrowed device pointers, plain sizes and a hipStream_t (passed as
+ * void*; NULL = the default stream), enqueues work asynchronously on that stream and returns
+ * 0 on success or a negative V2VAE_E* code.  Nothing here allocates, frees or synchronises;
+ * the caller owns every buffer, including the workspace (size from v2vae_workspace_bytes).
+ * No global state: calls on different streams / devices with different workspaces are independent.
+ *
+ * The reference has no FFI; the functions it exposes for this path are Python methods.  Each
+ * entry point cites the reference code whose arithmetic it replaces (paths under the reference
+ * checkout).
+ *
+ * Data model ("real-stacked"): ns real streams (ns = 1 real PAM, ns = 2 I/Q of complex QAM).
+ *   y        [ns][y_len]    received samples, row c = stream c (complex: Re, Im;
+ *                           lib/complex_equalization.py:677-681)
+ *   xhat     [ns][sym_cnt]  equalised symbols
+ *   levels, prior, scaling [ns][C]  amplitude levels / prior / learnable noise scaling per axis
+ * Raw parameters, mode 0 (real, lib/real_equalization.py:753-764, lib/torch_components.py:69-76):
+ *   h1 [L], h2 [L][L], k1 [l1], k2 [l2][l2]
+ * mode 1 (complex, holomorphic second-order kernels; Re plane then Im plane):
+ *   h1 [2][L], h2 [2][L][L], k1 [2][l1], k2 [2][l2][l2]
+ * l2 = 0 selects a linear FIR equaliser (lib/real_equalization.py:971-982) and k2 may be NULL.
+ */
+#ifndef V2VAE_HIP_H
+#define V2VAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define V2VAE_OK 0
+#define V2VAE_EINVAL (-1)   /* bad size / NULL pointer / unsupported combination */
+#define V2VAE_EHALO (-2)    /* local y / symbol range does not cover what the owned range needs */
+#define V2VAE_ELAUNCH (-3)  /* HIP reported a launch error */
+#define V2VAE_ESIZE (-4)    /* problem too large for the kernels' on-chip tiling */
+
+typedef struct v2vae_problem {
+    int32_t ns;      /* 1 or 2 */
+    int32_t mode;    /* 0 real (bug-compatible with lib/real_equalization.py:869), 1 complex */
+    int32_t sps;     /* samples per symbol S */
+    int32_t l1;      /* first-order equaliser taps */
+    int32_t pad1;    /* left zero padding of the first-order part (l1/2 for the Volterra equaliser,
+                        (l1-1)/2 for the Conv1d equaliser) */
+    int32_t l2;      /* second-order equaliser lags (odd) or 0 */
+    int32_t L;       /* channel memory */
+    int32_t C;       /* amplitude levels per stream (<= 16) */
+    int64_t n_glob;  /* samples of the whole batch; zero padding applies outside [0, n_glob) */
+    int64_t y_lo;    /* global sample index of y[.][0] */
+    int64_t y_len;   /* samples per stream held locally */
+    int64_t sym_lo;  /* first symbol for which xhat / moments are held locally */
+    int64_t sym_cnt; /* number of such symbols */
+    int64_t own_lo;  /* first owned symbol: owned symbols carry the KL term, per-symbol and equaliser
+                        gradients; windows n in [own_lo*sps, (own_lo+own_cnt)*sps) carry E and the
+                        channel-model gradients */
+    int64_t own_cnt;
+} v2vae_problem;
+
+/* Slots of the double-precision scalar block `scal` (8 doubles, device memory). */
+#define V2VAE_SCAL_E 0      /* exponent term E (lib/real_equalization.py:918), local then global sum */
+#define V2VAE_SCAL_KL 1     /* KL term (:847) */
+#define V2VAE_SCAL_LOSS 2   /* KL + W log E (:919) */
+#define V2VAE_SCAL_LAMBDA 3 /* W / E */
+#define V2VAE_SCAL_W 4      /* number of windows W = n_glob - L + 1 */
+#define V2VAE_SCAL_COUNT 8
+
+/* Bytes of workspace the calls below need for this problem (0 if the problem is invalid). */
+size_t v2vae_workspace_bytes(const v2vae_problem* p);
+
+/* Validate a problem description (sizes, halo coverage).  Returns a V2VAE_* code. */
+int v2vae_check_problem(const v2vae_problem* p);
+
+/* Raw parameters -> on-device coefficient tables in the workspace (symmetrised second-order
+ * kernels, lib/torch_components.py:94 and lib/real_equalization.py:841; per-phase compact channel
+ * taps).  Must precede the calls below whenever a parameter changed. */
+int v2vae_prep_tables(const v2vae_problem* p, const float* h1, const float* h2, const float* k1,
+                      const float* k2, void* ws, void* stream);
+
+/* Equaliser forward: SecondOrderVolterraSeries.forward (lib/torch_components.py:79-96) or the
+ * Conv1d equaliser (lib/real_equalization.py:980-982).  xhat [ns][sym_cnt]. */
+int v2vae_eq_fwd(const v2vae_problem* p, const float* y, const void* ws, float* xhat, void* stream);
+
+/* Soft demapping + per-symbol posterior moments + KL partial sums
+ * (lib/real_equalization.py:816-823, :847, :850-865).  q_out [ns][C][sym_cnt] may be NULL. */
+int v2vae_demap_moments(const v2vae_problem* p, const float* xhat, const float* levels,
+                        const float* prior, const float* scaling, const float* noise_var, void* ws,
+                        float* q_out, void* stream);
+
+/* Closed-form ELBO expectations over sliding windows, forward and (unscaled) backward in one pass
+ * (lib/real_equalization.py:868-918): partial sums of E, dE/d(channel kernels), dE/d(moments). */
+int v2vae_elbo_fused(const v2vae_problem* p, const float* y, void* ws, void* stream);
+
+/* Deterministic reduction of the E / KL partial sums of this rank into scal[E], scal[KL]. */
+int v2vae_reduce_scalars(const v2vae_problem* p, const void* ws, double* scal, void* stream);
+
+/* scal[LOSS] = KL + W log E, scal[LAMBDA] = W / E (lib/real_equalization.py:919), from global sums. */
+int v2vae_finalize_scalars(const v2vae_problem* p, double* scal, void* stream);
+
+/* d loss / d xhat for owned symbols (0 elsewhere) and noise-scaling gradient partials: backward
+ * of :816-865 given dE/d(moments) in the workspace.  grad_scale (device float, may be NULL = 1)
+ * multiplies everything (upstream gradient of the loss). */
+int v2vae_sym_bwd(const v2vae_problem* p, const float* xhat, const float* levels, const float* prior,
+                  const float* scaling, const float* noise_var, const double* scal,
+                  const float* grad_scale, void* ws, float* gxhat, void* stream);
+
+/* Equaliser backward: gradient partial sums of the first- and second-order kernels given gxhat
+ * (autograd of lib/torch_components.py:79-96). */
+int v2vae_eq_bwd(const v2vae_problem* p, const float* y, const float* gxhat, void* ws, void* stream);
+
+/* Reduce all partial sums and chain them to raw-parameter gradients.  Any output may be NULL.
+ * which: bit 0 = channel (g_h1, g_h2: scaled by scal[LAMBDA] and grad_scale), bit 1 = noise scaling
+ * (g_scaling [ns][C]), bit 2 = equaliser (g_k1, g_k2). */
+int v2vae_finish_grads(const v2vae_problem* p, void* ws, const double* scal, const float* grad_scale,
+                       int which, float* g_h1, float* g_h2, float* g_k1, float* g_k2,
+                       float* g_scaling, void* stream);
+
+/* Adam with AMSGrad on a flat parameter pack, torch.optim.Adam(amsgrad=True) arithmetic
+ * (lib/real_equalization.py:457-459); `step` is the 1-based step count.  If noise_var is not NULL
+ * it is set to E / W (:921-923); if loss_out is not NULL the loss is stored there as a float. */
+int v2vae_adam_amsgrad(int64_t n, float* params, const float* grads, float* m, float* v, float* vmax,
+                       float lr, float beta1, float beta2, float eps, int64_t step,
+                       const double* scal, float* noise_var, float* loss_out, void* stream);
+
+/* Hard decisions from posteriors: arg max over levels per stream (lib/utility.py:60-69).
+ * dec [ns][sym_cnt] int32 level indices, computed from xhat directly. */
+int v2vae_decide(const v2vae_problem* p, const float* xhat, const float* levels, const float* scaling,
+                 const float* noise_var, int32_t* dec, void* stream);
+
+/* Element counts of the five sections of the flat parameter pack [h1 | h2 | k1 | k2 | scaling]. */
+void v2vae_pack_sizes(const v2vae_problem* p, int64_t out[5]);
+
+typedef struct v2vae_train_args {
+    const float* y;       /* [ns][y_len] */
+    const float* levels;  /* [ns][C] */
+    const float* prior;   /* [ns][C] */
+    float* params;        /* flat pack, sections as in v2vae_pack_sizes */
+    float* grads;         /* same layout, overwritten */
+    float* adam_m;        /* Adam first moment, second moment, running max of the second moment */
+    float* adam_v;
+    float* adam_vmax;
+    float* noise_var;     /* device scalar, read by the soft demapper, then set to E / W if adaptive_noise */
+    void* ws;
+    double* scal;         /* V2VAE_SCAL_COUNT doubles */
+    float* xhat;          /* [ns][sym_cnt] out */
+    float* gxhat;         /* [ns][sym_cnt] scratch */
+    float* loss_out;      /* device float, may be NULL */
+    float lr, beta1, beta2, eps;
+    int64_t step;         /* 1-based Adam step count */
+    int32_t learn_scaling;   /* 0: the scaling section is not updated (lib/real_equalization.py:1014-1037) */
+    int32_t adaptive_noise;  /* lib/real_equalization.py:921-923 */
+} v2vae_train_args;
+
+/* One whole single-GPU training step of GenericTorchBlindEqualizer.fit's loop body
+ * (lib/real_equalization.py:488-496): forward, ELBO, backward, Adam-AMSGrad update, all enqueued
+ * on `stream` with no host synchronisation. */
+int v2vae_train_step(const v2vae_problem* p, const v2vae_train_args* a, void* stream);
+
+/* Read-only views into the workspace for tests and tooling: float offsets (in floats from the
+ * workspace base) of the per-symbol moments [ns][4][sym_cnt] and of dE/d(moments), same shape. */
+int64_t v2vae_ws_offset_moments(const v2vae_problem* p);
+int64_t v2vae_ws_offset_gmoments(const v2vae_problem* p);
+
+const char* v2vae_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

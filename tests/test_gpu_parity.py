@@ -1,0 +1,141 @@
+"""GPU parity: every stage of the HIP path, called through the C ABI, against the golden vectors
+of the reference (real PAM) and against the CPU oracle (complex QAM; parity unpinned by the
+reference, see oracle/v2vae_oracle.py).  Tolerances: 1e-5 relative (norm-wise) in fp32."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+STEP32 = sorted(os.path.basename(p)[len("v2vae_real_step_"):-4]
+                for p in glob.glob(os.path.join(GOLDEN, "v2vae_real_step_*f32.npz")))
+TOL = 1e-5
+
+
+def rel(a, b):
+    a = np.asarray(a.detach().cpu() if torch.is_tensor(a) else a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).cuda()
+
+
+def run_step(plan, y, h1, h2, k1, k2, levels, prior, scaling, nv, want_q=False):
+    """All stages through the C ABI; returns a dict of device tensors."""
+    from volterra_vae_amd import _lib
+    p = plan.p
+    xhat = torch.empty((p.ns, p.sym_cnt), dtype=torch.float32, device="cuda")
+    q = torch.empty((p.ns, p.C, p.sym_cnt), dtype=torch.float32, device="cuda") if want_q else None
+    plan.prep_tables(h1, h2, k1, k2)
+    plan.eq_fwd(y, xhat)
+    plan.demap_moments(xhat, levels, prior, scaling, nv, q)
+    plan.elbo_fused(y)
+    plan.reduce_scalars()
+    plan.finalize_scalars()
+    gx = plan.sym_bwd(xhat, levels, prior, scaling, nv)
+    plan.eq_bwd(y, gx)
+    g = dict(h1=torch.empty_like(h1), h2=torch.empty_like(h2), k1=torch.empty_like(k1),
+             k2=None if k2 is None else torch.empty_like(k2), sc=torch.empty_like(scaling))
+    plan.finish_grads(7, g["h1"], g["h2"], g["k1"], g["k2"], g["sc"])
+    torch.cuda.synchronize()
+    sc = plan.scal.cpu().numpy()
+    return dict(xhat=xhat, q=q, E=sc[_lib.SCAL_E], KL=sc[_lib.SCAL_KL], loss=sc[_lib.SCAL_LOSS], g=g, gx=gx)
+
+
+@pytest.mark.parametrize("name", STEP32)
+def test_real_step_matches_reference_golden(name):
+    from volterra_vae_amd.ops import Plan
+    g32 = np.load(os.path.join(GOLDEN, f"v2vae_real_step_{name}.npz"))
+    g64 = np.load(os.path.join(GOLDEN, f"v2vae_real_step_{name[:-3]}f64.npz"))
+    S, L, l1, l2, B = (int(g32[k]) for k in ("S", "L", "l1", "l2", "B"))
+    lin = bool(int(g32["linear_eq"]))
+    levels = dev(g32["constellation"][None, :])
+    prior = torch.ones_like(levels) / levels.shape[1]
+    y = dev(g32["rx"][None, :])
+    plan = Plan(ns=1, sps=S, l1=l1, pad1=(l1 - 1) // 2 if lin else l1 // 2, l2=0 if lin else l2, L=L,
+                C_levels=levels.shape[1], n_glob=B * S, device="cuda")
+    k1 = dev(g32["eq_w"].reshape(-1)) if lin else dev(g32["k1"])
+    k2 = None if lin else dev(g32["k2"])
+    nv = dev(np.array([float(g32["noise_variance_in"])]))
+    out = run_step(plan, y, dev(g32["h1"]), dev(g32["h2"]), k1, k2, levels, prior, dev(g32["noise_scaling"][None, :]), nv, True)
+    # Against the fp64 run of the reference: 1e-5 relative.  Against its fp32 run, the reference's own
+    # fp32 rounding (its distance to the fp64 run, up to 1e-5 on the equaliser gradients) is added.
+    def chk(ours, key, flat=False):
+        r64 = np.asarray(g64[key], dtype=np.float64)
+        r32 = np.asarray(g32[key], dtype=np.float64)
+        if flat:
+            r64, r32 = r64.reshape(-1), r32.reshape(-1)
+        own = np.linalg.norm(r32 - r64) / np.linalg.norm(r64)
+        e64, e32 = rel(ours, r64), rel(ours, r32)
+        print(f"{name} {key}: vs fp64 ref {e64:.2e}, vs fp32 ref {e32:.2e} (ref32-ref64 {own:.2e})")
+        # gradients that pass through the soft demapper inherit the fp32 rounding of xhat amplified by
+        # 2|x - a| / noise_variance; the reference's own fp32 run shows the same (its fp32-fp64 distance)
+        lim64 = TOL + own if key in ("g_k1", "g_k2", "g_eq_w", "g_noise_scaling") else TOL
+        assert e64 < lim64, f"{key}: {e64:.2e} vs fp64 reference"
+        assert e32 < TOL + own, f"{key}: {e32:.2e} vs fp32 reference (reference fp32-fp64 distance {own:.2e})"
+
+    chk(out["xhat"][0], "xhat")
+    chk(out["q"][0], "q")
+    chk(np.array([out["loss"]]), "loss")
+    chk(np.array([out["E"]]), "E")
+    chk(out["g"]["h1"], "g_h1")
+    chk(out["g"]["h2"], "g_h2")
+    if not int(g32["no_scaling"]):
+        chk(out["g"]["sc"][0], "g_noise_scaling")
+    if lin:
+        chk(out["g"]["k1"], "g_eq_w", flat=True)
+    else:
+        chk(out["g"]["k1"], "g_k1")
+        chk(out["g"]["k2"], "g_k2")
+
+
+def _complex_inputs(seed, L, S, l1, l2, B, M):
+    rng = np.random.default_rng(seed)
+    from volterra_vae_amd.synth import nonlinear_isi, qam_constellation
+    rx, _ = nonlinear_isi(B, qam_constellation(M * M), S, 16.0, rng)
+    y = np.stack((rx.real, rx.imag))
+    lv = np.arange(-(M - 1), M, 2).astype(float)
+    levels = np.stack((lv, lv))
+    prior = np.ones_like(levels) / M
+    scaling = 1.0 + 0.2 * rng.random((2, M))
+    h1 = 0.1 * rng.standard_normal((2, L)); h1[0, L // 2] += 1.0
+    h2 = 0.03 * rng.standard_normal((2, L, L))
+    k1 = 0.1 * rng.standard_normal((2, l1)); k1[0, l1 // 2] += 1.0
+    k2 = 0.02 * rng.standard_normal((2, l2, l2)) if l2 else None
+    return y, levels, prior, scaling, h1, h2, k1, k2
+
+
+@pytest.mark.parametrize("L,S,l1,l2,B,M", [(7, 2, 5, 3, 300, 4), (6, 1, 3, 0, 257, 2), (9, 3, 7, 5, 600, 4),
+                                           (25, 2, 25, 25, 1500, 4), (15, 2, 11, 9, 4000, 8)])
+def test_complex_step_matches_oracle(L, S, l1, l2, B, M):
+    from oracle import v2vae_oracle as orc
+    from volterra_vae_amd.ops import Plan
+    y, levels, prior, scaling, h1, h2, k1, k2 = _complex_inputs(3, L, S, l1, l2, B, M)
+    nv = 0.08
+    t = lambda a: torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    th1, th2, tk1, tsc = t(h1), t(h2), t(k1), t(scaling)
+    tk2 = t(k2) if k2 is not None else None
+    ty = torch.tensor(y)
+    xr = orc.complex_equaliser(ty, tk1[0], tk1[1], None if tk2 is None else tk2[0], None if tk2 is None else tk2[1], S)
+    loss, E, kl = orc.complex_v2vae_loss(xr, ty, th1[0], th1[1], th2[0], th2[1], torch.tensor(levels),
+                                         torch.tensor(prior), torch.tensor(nv, dtype=torch.float64), tsc, S)
+    loss.backward()
+    plan = Plan(ns=2, sps=S, l1=l1, pad1=l1 // 2, l2=l2, L=L, C_levels=M, n_glob=B * S, device="cuda")
+    out = run_step(plan, dev(y), dev(h1), dev(h2), dev(k1), None if k2 is None else dev(k2), dev(levels), dev(prior),
+                   dev(scaling), dev(np.array([nv])))
+    assert rel(out["xhat"], xr.detach().numpy()) < TOL
+    assert abs(out["loss"] - float(loss.detach())) < TOL * abs(float(loss.detach()))
+    assert abs(out["E"] - float(E.detach())) < TOL * abs(float(E.detach()))
+    assert abs(out["KL"] - float(kl.detach())) < TOL * abs(float(kl.detach())) + 1e-6
+    assert rel(out["g"]["h1"], th1.grad) < TOL
+    assert rel(out["g"]["h2"], th2.grad) < TOL
+    assert rel(out["g"]["k1"], tk1.grad) < TOL
+    assert rel(out["g"]["sc"], tsc.grad) < TOL
+    if k2 is not None:
+        assert rel(out["g"]["k2"], tk2.grad) < TOL

@@ -1,0 +1,1324 @@
+// V2VAE training hot path for MI355X (gfx950): equaliser forward/backward, soft demapping,
+// closed-form ELBO expectations over sliding windows (fused forward + backward), reductions,
+// chain rules back to raw parameters and Adam-AMSGrad.
+//
+// Generic path ("g" kernels): correct for every supported shape; the per-window vectors live in
+// LDS, coefficient tables are read through the scalar cache (wave-uniform addresses), per-block
+// partial sums are written to the workspace and reduced in a fixed order, so results are
+// bit-reproducible run to run.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+
+#include "v2vae_layout.h"
+
+namespace v2vae {
+
+static inline int64_t rup(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+int make_layout(const v2vae_problem* p, Lay* out) {
+    if (!p || !out) return V2VAE_EINVAL;
+    Lay l{};
+    l.ns = p->ns; l.mode = p->mode; l.S = p->sps; l.l1 = p->l1; l.pad1 = p->pad1; l.l2 = p->l2;
+    l.L = p->L; l.C = p->C;
+    l.n_glob = p->n_glob; l.y_lo = p->y_lo; l.y_len = p->y_len; l.sym_lo = p->sym_lo;
+    l.sym_cnt = p->sym_cnt; l.own_lo = p->own_lo; l.own_cnt = p->own_cnt;
+    if (l.ns < 1 || l.ns > 2) return V2VAE_EINVAL;
+    if ((l.mode == 0) != (l.ns == 1)) return V2VAE_EINVAL;
+    if (l.S < 1 || l.S > 8) return V2VAE_EINVAL;
+    if (l.L < 2 || l.S > l.L) return V2VAE_EINVAL;  // assert S <= L: lib/real_equalization.py:751
+    if (l.l1 < 1 || l.l1 > 255 || l.pad1 < 0 || l.pad1 >= l.l1) return V2VAE_EINVAL;
+    if (l.l2 < 0 || l.l2 > 129 || (l.l2 > 0 && (l.l2 % 2) == 0)) return V2VAE_EINVAL;  // odd lags: torch_components.py:65-66
+    if (l.C < 1 || l.C > MAX_C) return V2VAE_EINVAL;
+    if (l.n_glob < l.L || l.n_glob % l.S != 0) return V2VAE_EINVAL;
+    l.b_glob = l.n_glob / l.S;
+    l.W = l.n_glob - l.L + 1;
+    l.pre = (l.L - 1) / 2;
+    l.kl_lo = l.pre;
+    l.kl_hi = l.b_glob - l.L / 2;  // Python -(L-1)//2 == -(L/2)
+    if (l.kl_hi < l.kl_lo) l.kl_hi = l.kl_lo;
+    l.kmax = (l.S - 1 + l.L - 1) / l.S;
+    l.LE = l.kmax + 1;
+    l.LEp = (int)rup(l.LE, 4);
+    l.LTp = l.ns * l.LEp;
+    l.p2 = l.l2 / 2;
+    l.LT2 = l.ns * l.l2;
+    l.LT2p = (int)rup(l.LT2, 4);
+    {
+        int left = l.pad1 > l.p2 ? l.pad1 : l.p2;
+        int right1 = l.l1 - 1 - l.pad1;
+        int right = right1 > l.p2 ? right1 : l.p2;
+        l.hl = left + 4;  // +4: padded stacked lags read (finite) samples just left of the halo
+        l.hr = right;
+        l.tile_len = EQ_TB * l.S + l.hl + l.hr + 1;
+    }
+    // ---- range checks (halo contract)
+    if (l.sym_cnt < 1 || l.own_cnt < 1 || l.y_len < 1) return V2VAE_EINVAL;
+    if (l.sym_lo < 0 || l.sym_lo + l.sym_cnt > l.b_glob) return V2VAE_EINVAL;
+    if (l.own_lo < l.sym_lo || l.own_lo + l.own_cnt > l.sym_lo + l.sym_cnt) return V2VAE_EINVAL;
+    {
+        int64_t need_lo = l.own_lo - l.kmax; if (need_lo < 0) need_lo = 0;
+        int64_t need_hi = l.own_lo + l.own_cnt + l.kmax; if (need_hi > l.b_glob) need_hi = l.b_glob;
+        if (l.sym_lo > need_lo || l.sym_lo + l.sym_cnt < need_hi) return V2VAE_EHALO;
+        int64_t ys_lo = l.sym_lo * l.S - (l.hl - 4); if (ys_lo < 0) ys_lo = 0;
+        int64_t ys_hi = (l.sym_lo + l.sym_cnt - 1) * l.S + l.hr + 1; if (ys_hi > l.n_glob) ys_hi = l.n_glob;
+        // y' of every window this rank evaluates: n in [(own_lo-kmax)*S, (own_lo+own_cnt)*S), sample pre+n
+        int64_t yw_lo = (l.own_lo - l.kmax) * l.S + l.pre; if (yw_lo < 0) yw_lo = 0;
+        int64_t yw_hi = (l.own_lo + l.own_cnt) * l.S + l.pre; if (yw_hi > l.n_glob) yw_hi = l.n_glob;
+        if (yw_lo < ys_lo) ys_lo = yw_lo;
+        if (yw_hi > ys_hi) ys_hi = yw_hi;
+        if (l.y_lo > ys_lo || l.y_lo + l.y_len < ys_hi) return V2VAE_EHALO;
+        if (l.y_lo < 0 || l.y_lo + l.y_len > l.n_glob) return V2VAE_EINVAL;
+    }
+    // ---- ELBO tiling: largest window tile whose LDS image fits
+    l.TWIN = 0;
+    for (int tw = 256; tw >= 64; tw >>= 1) {
+        int ts = tw - l.kmax;
+        if (ts < tw / 4) continue;
+        int tsym = tw + l.kmax + 4;
+        int64_t fl = (int64_t)l.ns * 4 * tsym + 3 * l.ns * tw + 2 * tw + 2 * (int64_t)l.ns * l.LTp * tw +
+                     3 * (int64_t)l.LTp * tw + (int64_t)l.ns * 5 * NT + SCRATCH_F;
+        if (fl * 4 <= LDS_BUDGET) { l.TWIN = tw; l.TS = ts; l.TSYM = tsym; l.lds_elbo = (int)(fl * 4); break; }
+    }
+    if (l.TWIN == 0) return V2VAE_ESIZE;
+    l.NG = NT / l.TWIN;
+    l.ntile_elbo = (int)((l.own_cnt + l.TS - 1) / l.TS);
+    l.nblk_elbo = l.ntile_elbo < MAX_BLOCKS ? l.ntile_elbo : MAX_BLOCKS;
+    {
+        int nb = l.LTp / 4;
+        l.nG_elbo = l.ns * nb * nb;
+        l.nitems_elbo = l.nG_elbo + nb * nb;
+        if (l.nitems_elbo <= NT) { l.nchunk_elbo = NT / l.nitems_elbo; l.maxi_elbo = 1; }
+        else { l.nchunk_elbo = 1; l.maxi_elbo = (l.nitems_elbo + NT - 1) / NT; }
+        if (l.maxi_elbo > 4) return V2VAE_ESIZE;
+        if (l.nchunk_elbo > 16) l.nchunk_elbo = 16;
+        if (l.ns * l.LTp > NT) return V2VAE_ESIZE;
+    }
+    // ---- equaliser tiling
+    l.ntile_eq = (int)((l.own_cnt + EQ_TB - 1) / EQ_TB);
+    l.nblk_eq = l.ntile_eq < MAX_BLOCKS ? l.ntile_eq : MAX_BLOCKS;
+    {
+        int nb = l.LT2p / 4;
+        l.nitems_eq = l.ns * nb * nb;
+        if (l.nitems_eq == 0) { l.nchunk_eq = 1; l.maxi_eq = 1; }
+        else if (l.nitems_eq <= NT) { l.nchunk_eq = NT / l.nitems_eq; l.maxi_eq = 1; }
+        else { l.nchunk_eq = 1; l.maxi_eq = (l.nitems_eq + NT - 1) / NT; }
+        if (l.maxi_eq > 10) return V2VAE_ESIZE;
+        if (l.nchunk_eq > 16) l.nchunk_eq = 16;
+        l.nk1 = l.ns * l.ns * l.l1;
+        if (l.nk1 > 4 * NT) return V2VAE_ESIZE;
+        int64_t fl = (int64_t)l.ns * l.tile_len + (int64_t)l.ns * EQ_TB + SCRATCH_F;
+        if (fl * 4 > LDS_BUDGET) return V2VAE_ESIZE;
+        l.lds_eq = (int)(fl * 4);
+    }
+    {
+        int64_t nb = (l.sym_cnt + NT - 1) / NT;
+        l.nblk_sym = (int)(nb < 1024 ? nb : 1024);
+    }
+    l.rec_elbo = l.S * rec_elbo_phase(l);
+    l.rec_eq = l.ns * l.LT2p * l.LT2p + l.nk1;
+    l.rec_sym = l.ns * l.C;
+    // ---- workspace carve (floats, every region 64-float aligned)
+    int64_t o = 0;
+    auto take = [&](int64_t n) { int64_t r = o; o += rup(n, 64); return r; };
+    l.o_eqK1 = take(l.nk1);
+    l.o_eqK2 = take((int64_t)l.ns * l.LT2p * l.LT2p);
+    l.o_h1c = take((int64_t)l.S * l.ns * l.LTp);
+    l.o_Hc = take((int64_t)l.S * l.ns * l.LTp * l.LTp);
+    l.o_HHc = take((int64_t)l.S * l.ns * l.LTp * l.LTp);
+    l.o_dc = take((int64_t)l.S * l.ns * l.LTp);
+    l.o_dqc = take((int64_t)l.S * l.ns * l.LTp);
+    l.o_mom = take((int64_t)l.ns * 4 * l.sym_cnt);
+    l.o_gmom = take((int64_t)l.ns * 4 * l.sym_cnt);
+    l.o_part_elbo = take((int64_t)l.nblk_elbo * l.rec_elbo);
+    l.o_part_eq = take((int64_t)l.nblk_eq * l.rec_eq);
+    l.o_part_sym = take((int64_t)l.nblk_sym * l.rec_sym);
+    l.o_tot_elbo = take(l.rec_elbo);
+    l.o_tot_eq = take(l.rec_eq);
+    l.o_tot_sym = take(l.rec_sym);
+    l.o_Epart = take(2 * (int64_t)l.nblk_elbo);
+    l.o_KLpart = take(2 * (int64_t)l.nblk_sym);
+    l.total_floats = o;
+    *out = l;
+    return V2VAE_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float stacked_quad(int mode, const float* __restrict__ h2, int L, int o, int a, int b) {
+    // effective symmetric second-order kernel of output o on the real-stacked tap vector
+    if (mode == 0) return h2[a * L + b] + h2[b * L + a];
+    const int ca = a >= L, ia = a - ca * L, cb = b >= L, ib = b - cb * L;
+    const float* hr = h2;
+    const float* hi = h2 + (size_t)L * L;
+    const float Hr = hr[ia * L + ib] + hr[ib * L + ia];
+    const float Hi = hi[ia * L + ib] + hi[ib * L + ia];
+    if (o == 0) return (ca == cb) ? (ca == 0 ? Hr : -Hr) : -Hi;
+    return (ca == cb) ? (ca == 0 ? Hi : -Hi) : Hr;
+}
+
+__device__ __forceinline__ float stacked_lin(int mode, const float* __restrict__ h1, int L, int o, int a) {
+    if (mode == 0) return h1[a];
+    const int ca = a >= L, ia = a - ca * L;
+    if (o == 0) return ca == 0 ? h1[ia] : -h1[L + ia];
+    return ca == 0 ? h1[L + ia] : h1[ia];
+}
+
+// compact tap k of phase r -> stacked original tap index c*L + i, or -1
+__device__ __forceinline__ int tap_index(const Lay& l, int r, int k) {
+    const int c = k / l.LEp, kk = k - c * l.LEp;
+    if (kk >= l.LE) return -1;
+    const int i = r + l.L - 1 - kk * l.S;
+    if (i < 0 || i >= l.L) return -1;
+    return c * l.L + i;
+}
+
+// original tap (stream c, index i) -> phase r and compact index k
+__device__ __forceinline__ void tap_to_compact(const Lay& l, int a, int* r, int* k) {
+    const int c = a / l.L, i = a - c * l.L;
+    int rr = (i - (l.L - 1)) % l.S;
+    if (rr < 0) rr += l.S;
+    *r = rr;
+    *k = c * l.LEp + (rr + l.L - 1 - i) / l.S;
+}
+
+__device__ __forceinline__ double block_sum_double(double v, double* red /* >= NT/64 doubles of LDS */) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wv] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x == 0) for (int i = 0; i < NT / 64; ++i) s += red[i];
+    return s;  // valid in thread 0
+}
+
+// ------------------------------------------------------------------------------------------
+// tables
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_prep_tables(Lay l, const float* __restrict__ h1, const float* __restrict__ h2,
+                                                    const float* __restrict__ k1, const float* __restrict__ k2,
+                                                    float* __restrict__ ws) {
+    const int tid = blockIdx.x * NT + threadIdx.x, nth = gridDim.x * NT;
+    for (int idx = tid; k1 && idx < l.nk1; idx += nth) {
+        const int o = idx / (l.ns * l.l1), rem = idx - o * l.ns * l.l1;
+        ws[l.o_eqK1 + idx] = stacked_lin(l.mode, k1, l.l1, o, rem);
+    }
+    const int n2 = l.ns * l.LT2p * l.LT2p;
+    for (int idx = tid; k1 && idx < n2; idx += nth) {
+        const int o = idx / (l.LT2p * l.LT2p), rem = idx - o * l.LT2p * l.LT2p;
+        const int a = rem / l.LT2p, b = rem - a * l.LT2p;
+        ws[l.o_eqK2 + idx] = (a < l.LT2 && b < l.LT2) ? stacked_quad(l.mode, k2, l.l2, o, a, b) : 0.f;
+    }
+    const int nv = l.S * l.ns * l.LTp;
+    for (int idx = tid; h1 && idx < nv; idx += nth) {
+        const int r = idx / (l.ns * l.LTp), rem = idx - r * l.ns * l.LTp;
+        const int o = rem / l.LTp, k = rem - o * l.LTp;
+        const int a = tap_index(l, r, k);
+        float hv = 0.f, dv = 0.f, dqv = 0.f;
+        if (a >= 0) {
+            hv = stacked_lin(l.mode, h1, l.L, o, a);
+            dv = stacked_quad(l.mode, h2, l.L, o, a, a);
+            dqv = (l.mode == 0) ? h2[a * l.L + a] : dv;  // lib/real_equalization.py:869 uses diag(h2)
+        }
+        ws[l.o_h1c + idx] = hv;
+        ws[l.o_dc + idx] = dv;
+        ws[l.o_dqc + idx] = dqv;
+    }
+    const int nm = l.S * l.ns * l.LTp * l.LTp;
+    for (int idx = tid; h1 && idx < nm; idx += nth) {
+        const int ro = idx / (l.LTp * l.LTp), rem = idx - ro * l.LTp * l.LTp;
+        const int r = ro / l.ns, o = ro - r * l.ns;
+        const int k = rem / l.LTp, j = rem - k * l.LTp;
+        const int a = tap_index(l, r, k), b = tap_index(l, r, j);
+        const float hv = (a >= 0 && b >= 0) ? stacked_quad(l.mode, h2, l.L, o, a, b) : 0.f;
+        ws[l.o_Hc + idx] = hv;
+        ws[l.o_HHc + idx] = hv * hv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// equaliser forward
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_sample_tile(const Lay& l, const float* __restrict__ y, int64_t g0, float* tile) {
+    // tile[c][i] = y_c[g0 + i] (0 outside the batch), i in [0, tile_len)
+    const int n = l.ns * l.tile_len;
+    for (int idx = threadIdx.x; idx < n; idx += NT) {
+        const int c = idx / l.tile_len, i = idx - c * l.tile_len;
+        const int64_t g = g0 + i;
+        float v = 0.f;
+        if (g >= 0 && g < l.n_glob) {
+            const int64_t loc = g - l.y_lo;
+            if (loc >= 0 && loc < l.y_len) v = y[(int64_t)c * l.y_len + loc];
+        }
+        tile[idx] = v;
+    }
+}
+
+__global__ __launch_bounds__(NT) void k_eq_fwd(Lay l, const float* __restrict__ y, const float* __restrict__ ws,
+                                               float* __restrict__ xhat) {
+    extern __shared__ float sm[];
+    float* tile = sm;
+    const int64_t b0 = l.sym_lo + (int64_t)blockIdx.x * EQ_TB;
+    load_sample_tile(l, y, b0 * l.S - l.hl, tile);
+    __syncthreads();
+    const int64_t b = b0 + threadIdx.x;
+    if (b >= l.sym_lo + l.sym_cnt) return;
+    const int base = threadIdx.x * l.S + l.hl;
+    const float* __restrict__ K1 = ws + l.o_eqK1;
+    const float* __restrict__ K2 = ws + l.o_eqK2;
+    float out[2] = {0.f, 0.f};
+    for (int c = 0; c < l.ns; ++c)
+        for (int j = 0; j < l.l1; ++j) {
+            const float x = tile[c * l.tile_len + base - l.pad1 + j];
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+                if (o < l.ns) out[o] = fmaf(K1[(o * l.ns + c) * l.l1 + j], x, out[o]);
+        }
+    if (l.l2 > 0) {
+        const int nb = l.LT2p / 4;
+        for (int ib = 0; ib < nb; ++ib) {
+            float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            for (int c = 0; c < l.ns; ++c)
+                for (int j = 0; j < l.l2; ++j) {
+                    const float x = tile[c * l.tile_len + base + l.p2 - j];
+                    const int ip = c * l.l2 + j;
+#pragma unroll
+                    for (int o = 0; o < 2; ++o)
+                        if (o < l.ns) {
+                            const float4 kv = *reinterpret_cast<const float4*>(K2 + ((size_t)o * l.LT2p + ip) * l.LT2p + ib * 4);
+                            acc[o][0] = fmaf(kv.x, x, acc[o][0]);
+                            acc[o][1] = fmaf(kv.y, x, acc[o][1]);
+                            acc[o][2] = fmaf(kv.z, x, acc[o][2]);
+                            acc[o][3] = fmaf(kv.w, x, acc[o][3]);
+                        }
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ii = ib * 4 + i;
+                if (ii < l.LT2) {
+                    const int c = ii / l.l2, j = ii - c * l.l2;
+                    const float xi = tile[c * l.tile_len + base + l.p2 - j];
+#pragma unroll
+                    for (int o = 0; o < 2; ++o)
+                        if (o < l.ns) out[o] = fmaf(xi, acc[o][i], out[o]);
+                }
+            }
+        }
+    }
+    for (int o = 0; o < l.ns; ++o) xhat[(int64_t)o * l.sym_cnt + (b - l.sym_lo)] = out[o];
+}
+
+// ------------------------------------------------------------------------------------------
+// soft demapping, moments, KL
+// ------------------------------------------------------------------------------------------
+struct Posterior {
+    float q[MAX_C];
+    float mu, var, kap, gam;
+};
+
+__device__ __forceinline__ void posterior(float x, const float* __restrict__ lv, const float* __restrict__ sc, int C,
+                                          float nv, Posterior& p) {
+    // Logits reach |z| ~ 1e2..1e3 for small noise variance; rounding them to fp32 before the max is
+    // subtracted would put ~|z| * 6e-8 of absolute error into the exponent, i.e. that much RELATIVE
+    // error into q.  The difference z - max is therefore formed in double and only then rounded.
+    double zd[MAX_C];
+    double mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < MAX_C; ++i)
+        if (i < C) {
+            const double d = (double)x - (double)lv[i];
+            zd[i] = -(d * d) / ((double)nv * (double)sc[i]);
+            mx = fmax(mx, zd[i]);
+        }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAX_C; ++i)
+        if (i < C) {
+            p.q[i] = expf((float)(zd[i] - mx));
+            sum += p.q[i];
+        }
+    const float inv = 1.f / sum;
+    float mu = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAX_C; ++i)
+        if (i < C) {
+            p.q[i] *= inv;
+            mu = fmaf(p.q[i], lv[i], mu);
+        }
+    float v = 0.f, k3 = 0.f, c4 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAX_C; ++i)
+        if (i < C) {
+            const float d = lv[i] - mu, d2 = d * d;
+            v = fmaf(p.q[i], d2, v);
+            k3 = fmaf(p.q[i], d2 * d, k3);
+            c4 = fmaf(p.q[i], d2 * d2, c4);
+        }
+    p.mu = mu; p.var = v; p.kap = k3; p.gam = c4 - 3.f * v * v;
+}
+
+__global__ __launch_bounds__(NT) void k_demap_moments(Lay l, const float* __restrict__ xhat, const float* __restrict__ levels,
+                                                      const float* __restrict__ prior, const float* __restrict__ scaling,
+                                                      const float* __restrict__ noise_var, float* __restrict__ ws,
+                                                      float* __restrict__ q_out) {
+    __shared__ double red[NT / 64];
+    const float nv = noise_var[0];
+    float* __restrict__ mom = ws + l.o_mom;
+    double kl = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < l.sym_cnt; i += (int64_t)gridDim.x * NT) {
+        const int64_t b = l.sym_lo + i;
+        const bool in_kl = b >= l.kl_lo && b < l.kl_hi && b >= l.own_lo && b < l.own_lo + l.own_cnt;
+        for (int c = 0; c < l.ns; ++c) {
+            Posterior p;
+            posterior(xhat[(int64_t)c * l.sym_cnt + i], levels + c * l.C, scaling + c * l.C, l.C, nv, p);
+            float* m = mom + (int64_t)c * 4 * l.sym_cnt + i;
+            m[0] = p.mu; m[l.sym_cnt] = p.var; m[2 * l.sym_cnt] = p.kap; m[3 * l.sym_cnt] = p.gam;
+            float klb = 0.f;
+#pragma unroll
+            for (int k = 0; k < MAX_C; ++k)
+                if (k < l.C) {
+                    if (q_out) q_out[((int64_t)c * l.C + k) * l.sym_cnt + i] = p.q[k];
+                    klb += p.q[k] * logf(p.q[k] / prior[c * l.C + k] + 1e-12f);
+                }
+            if (in_kl) kl += (double)klb;
+        }
+    }
+    const double s = block_sum_double(kl, red);
+    if (threadIdx.x == 0) reinterpret_cast<double*>(ws + l.o_KLpart)[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(NT) void k_decide(Lay l, const float* __restrict__ xhat, const float* __restrict__ levels,
+                                               const float* __restrict__ scaling, const float* __restrict__ noise_var,
+                                               int32_t* __restrict__ dec) {
+    const float nv = noise_var[0];
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < l.sym_cnt * l.ns; i += (int64_t)gridDim.x * NT) {
+        const int c = (int)(i / l.sym_cnt);
+        const float x = xhat[i];
+        float best = -INFINITY;
+        int arg = 0;
+        for (int k = 0; k < l.C; ++k) {
+            const float d = x - levels[c * l.C + k];
+            const float z = -(d * d) / (nv * scaling[c * l.C + k]);
+            if (z > best) { best = z; arg = k; }
+        }
+        dec[i] = arg;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// per-symbol backward
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_sym_bwd(Lay l, const float* __restrict__ xhat, const float* __restrict__ levels,
+                                                const float* __restrict__ prior, const float* __restrict__ scaling,
+                                                const float* __restrict__ noise_var, const double* __restrict__ scal,
+                                                const float* __restrict__ grad_scale, float* __restrict__ ws,
+                                                float* __restrict__ gxhat) {
+    __shared__ float red[NT / 64][2 * MAX_C];
+    const float nv = noise_var[0];
+    const float lam = (float)scal[V2VAE_SCAL_LAMBDA];
+    const float gsc = grad_scale ? grad_scale[0] : 1.f;
+    const float* __restrict__ gmom = ws + l.o_gmom;
+    float gs[2][MAX_C];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int k = 0; k < MAX_C; ++k) gs[c][k] = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < l.sym_cnt; i += (int64_t)gridDim.x * NT) {
+        const int64_t b = l.sym_lo + i;
+        const bool own = b >= l.own_lo && b < l.own_lo + l.own_cnt;
+        const bool in_kl = own && b >= l.kl_lo && b < l.kl_hi;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            if (c < l.ns) {
+                float gx = 0.f;
+                if (own) {
+                    const float x = xhat[(int64_t)c * l.sym_cnt + i];
+                    const float* lv = levels + c * l.C;
+                    const float* sc = scaling + c * l.C;
+                    Posterior p;
+                    posterior(x, lv, sc, l.C, nv, p);
+                    const float* g = gmom + (int64_t)c * 4 * l.sym_cnt + i;
+                    const float gmu = g[0], gv = g[l.sym_cnt], gk = g[2 * l.sym_cnt], gg = g[3 * l.sym_cnt];
+                    // Softmax backward cancels dq against its posterior mean; for peaked posteriors the
+                    // difference is many orders below dq itself, so this short chain runs in double.
+                    double dq[MAX_C];
+                    double qdq = 0.0;
+#pragma unroll
+                    for (int k = 0; k < MAX_C; ++k)
+                        if (k < l.C) {
+                            const double d = (double)lv[k] - (double)p.mu, d2 = d * d;
+                            double v = (double)gmu * d + (double)gv * d2 + (double)gk * (d2 * d - 3.0 * (double)p.var * d) +
+                                       (double)gg * (d2 * d2 - 4.0 * (double)p.kap * d - 6.0 * (double)p.var * d2);
+                            v *= (double)lam;
+                            if (in_kl) {
+                                const float pr = prior[c * l.C + k];
+                                v += (double)(logf(p.q[k] / pr + 1e-12f) + p.q[k] / (p.q[k] + 1e-12f * pr));
+                            }
+                            v *= (double)gsc;
+                            dq[k] = v;
+                            qdq += (double)p.q[k] * v;
+                        }
+                    double gxd = 0.0;
+#pragma unroll
+                    for (int k = 0; k < MAX_C; ++k)
+                        if (k < l.C) {
+                            const double dz = (double)p.q[k] * (dq[k] - qdq);
+                            const double df = (double)x - (double)lv[k];
+                            const double den = (double)nv * (double)sc[k];
+                            gxd += dz * (-2.0 * df / den);
+                            gs[c][k] += (float)(dz * df * df / (den * (double)sc[k]));
+                        }
+                    gx = (float)gxd;
+                }
+                gxhat[(int64_t)c * l.sym_cnt + i] = gx;
+            }
+    }
+    // deterministic block reduction of the noise-scaling gradient
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int k = 0; k < MAX_C; ++k) {
+            float v = gs[c][k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0) red[wv][c * MAX_C + k] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < l.ns * l.C) {
+        const int c = threadIdx.x / l.C, k = threadIdx.x - c * l.C;
+        float s = 0.f;
+        for (int w = 0; w < NT / 64; ++w) s += red[w][c * MAX_C + k];
+        ws[l.o_part_sym + (int64_t)blockIdx.x * l.rec_sym + threadIdx.x] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// equaliser backward (persistent workgroups; partial sums per workgroup)
+// ------------------------------------------------------------------------------------------
+template <int MAXI>
+__global__ __launch_bounds__(NT) void k_eq_bwd(Lay l, const float* __restrict__ y, const float* __restrict__ gx,
+                                               float* __restrict__ ws) {
+    extern __shared__ float sm[];
+    float* tile = sm;
+    float* gt = tile + l.ns * l.tile_len;
+    float* scratch = gt + l.ns * EQ_TB;
+    const int tid = threadIdx.x;
+    const int nb = l.LT2p / 4;
+    // work assignment
+    int item0, chunk, nchunk = l.nchunk_eq;
+    if (MAXI == 1 && l.nitems_eq > 0 && l.nitems_eq <= NT) { item0 = tid % l.nitems_eq; chunk = tid / l.nitems_eq; }
+    else { item0 = tid; chunk = 0; }
+    const bool active = chunk < nchunk;
+    float acc[MAXI][16];
+#pragma unroll
+    for (int s = 0; s < MAXI; ++s)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[s][e] = 0.f;
+    float acc1[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int t = blockIdx.x; t < l.ntile_eq; t += gridDim.x) {
+        const int64_t b0 = l.own_lo + (int64_t)t * EQ_TB;
+        const int64_t rem = l.own_lo + l.own_cnt - b0;
+        const int nbs = rem < EQ_TB ? (int)rem : EQ_TB;
+        __syncthreads();
+        load_sample_tile(l, y, b0 * l.S - l.hl, tile);
+        for (int idx = tid; idx < l.ns * EQ_TB; idx += NT) {
+            const int o = idx / EQ_TB, i = idx - o * EQ_TB;
+            gt[idx] = i < nbs ? gx[(int64_t)o * l.sym_cnt + (b0 + i - l.sym_lo)] : 0.f;
+        }
+        __syncthreads();
+        if (active && l.nitems_eq > 0) {
+#pragma unroll
+            for (int s = 0; s < MAXI; ++s) {
+                const int it = item0 + s * NT;
+                if (it < l.nitems_eq) {
+                    const int o = it / (nb * nb), r2 = it - o * nb * nb;
+                    const int ib = r2 / nb, jb = r2 - ib * nb;
+                    int offr[4], offc[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        int ii = ib * 4 + e;
+                        int c = ii < l.LT2 ? ii / l.l2 : l.ns - 1;
+                        int j = ii < l.LT2 ? ii - c * l.l2 : l.l2 + (ii - l.LT2);
+                        offr[e] = c * l.tile_len + l.hl + l.p2 - j;
+                        ii = jb * 4 + e;
+                        c = ii < l.LT2 ? ii / l.l2 : l.ns - 1;
+                        j = ii < l.LT2 ? ii - c * l.l2 : l.l2 + (ii - l.LT2);
+                        offc[e] = c * l.tile_len + l.hl + l.p2 - j;
+                    }
+                    for (int bl = chunk; bl < nbs; bl += nchunk) {
+                        const float g = gt[o * EQ_TB + bl];
+                        const int sb = bl * l.S;
+                        float xr[4], xc[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { xr[e] = g * tile[offr[e] + sb]; xc[e] = tile[offc[e] + sb]; }
+#pragma unroll
+                        for (int a = 0; a < 4; ++a)
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) acc[s][a * 4 + b] = fmaf(xr[a], xc[b], acc[s][a * 4 + b]);
+                    }
+                }
+            }
+        }
+        // first-order kernel gradient
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int it = tid + s * NT;
+            if (it < l.nk1) {
+                const int o = it / (l.ns * l.l1), r2 = it - o * l.ns * l.l1;
+                const int c = r2 / l.l1, j = r2 - c * l.l1;
+                const int off = c * l.tile_len + l.hl - l.pad1 + j;
+                float a1 = acc1[s];
+                for (int bl = 0; bl < nbs; ++bl) a1 = fmaf(gt[o * EQ_TB + bl], tile[off + bl * l.S], a1);
+                acc1[s] = a1;
+            }
+        }
+    }
+    // flush
+    float* part = ws + l.o_part_eq + (int64_t)blockIdx.x * l.rec_eq;
+    __syncthreads();
+    if (l.nitems_eq > 0) {
+        if (MAXI == 1 && l.nitems_eq <= NT) {
+            for (int base = 0; base < nchunk; base += 1) {
+                // one chunk at a time through scratch keeps the LDS need at nitems*16 floats
+                __syncthreads();
+                if (active && chunk == base)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) scratch[item0 * 16 + e] = (base == 0 ? 0.f : scratch[item0 * 16 + e]) + acc[0][e];
+            }
+            __syncthreads();
+            for (int idx = tid; idx < l.nitems_eq * 16; idx += NT) {
+                const int it = idx / 16, e = idx - it * 16;
+                const int o = it / (nb * nb), r2 = it - o * nb * nb;
+                const int ib = r2 / nb, jb = r2 - ib * nb;
+                part[((size_t)o * l.LT2p + ib * 4 + e / 4) * l.LT2p + jb * 4 + (e & 3)] = scratch[idx];
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < MAXI; ++s) {
+                const int it = item0 + s * NT;
+                if (it < l.nitems_eq) {
+                    const int o = it / (nb * nb), r2 = it - o * nb * nb;
+                    const int ib = r2 / nb, jb = r2 - ib * nb;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        part[((size_t)o * l.LT2p + ib * 4 + e / 4) * l.LT2p + jb * 4 + (e & 3)] = acc[s][e];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int it = tid + s * NT;
+        if (it < l.nk1) part[(size_t)l.ns * l.LT2p * l.LT2p + it] = acc1[s];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fused ELBO forward + backward over sliding windows (polyphase form)
+// ------------------------------------------------------------------------------------------
+template <int MAXI>
+__global__ __launch_bounds__(NT) void k_elbo(Lay l, const float* __restrict__ y, float* __restrict__ ws) {
+    extern __shared__ float sm[];
+    const int TW = l.TWIN, TSYM = l.TSYM, LTp = l.LTp, NS = l.ns, NG = l.NG;
+    float* s_mom = sm;                       // [NS][4][TSYM]
+    float* s_yw = s_mom + NS * 4 * TSYM;     // [NS][TW]  y' (0 if window invalid)
+    float* s_ev = s_yw + NS * TW;            // [NS][TW]  residual e = A - y' (0 if invalid)
+    float* s_Av = s_ev + NS * TW;            // [NS][TW]  A (0 if invalid)
+    float* s_ow = s_Av + NS * TW;            // [TW] 1 if the window is owned and valid
+    float* s_vl = s_ow + TW;                 // [TW] 1 if the window is valid
+    float* s_z = s_vl + TW;                  // [NS][LTp][TW]
+    float* s_w = s_z + NS * LTp * TW;        // [NS][LTp][TW]
+    float* s_Dmu = s_w + NS * LTp * TW;      // [LTp][TW]
+    float* s_Dv = s_Dmu + LTp * TW;
+    float* s_Dk = s_Dv + LTp * TW;
+    float* s_red = s_Dk + LTp * TW;          // [NS][5][NG][TW]
+    float* scratch = s_red + NS * 5 * NT;    // SCRATCH_F
+    __shared__ double dred[NT / 64];
+
+    const int tid = threadIdx.x;
+    const int ts = tid % TW;
+    const int g = __builtin_amdgcn_readfirstlane(tid / TW);  // TW >= 64: uniform per wave
+    const int nb = LTp / 4;
+    const float* __restrict__ mom = ws + l.o_mom;
+    float* __restrict__ gmom = ws + l.o_gmom;
+    const int64_t own_hi = l.own_lo + l.own_cnt;
+    const int64_t sym_hi = l.sym_lo + l.sym_cnt;
+
+    int item0, chunk;
+    const int nchunk = l.nchunk_elbo;
+    if (MAXI == 1 && l.nitems_elbo <= NT) { item0 = tid % l.nitems_elbo; chunk = tid / l.nitems_elbo; }
+    else { item0 = tid; chunk = 0; }
+    const bool active = chunk < nchunk;
+
+    double Eacc = 0.0;
+    for (int r = 0; r < l.S; ++r) {
+        const float* __restrict__ Hc = ws + l.o_Hc + (size_t)r * NS * LTp * LTp;
+        const float* __restrict__ HHc = ws + l.o_HHc + (size_t)r * NS * LTp * LTp;
+        const float* __restrict__ h1c = ws + l.o_h1c + (size_t)r * NS * LTp;
+        const float* __restrict__ dc = ws + l.o_dc + (size_t)r * NS * LTp;
+        const float* __restrict__ dqc = ws + l.o_dqc + (size_t)r * NS * LTp;
+        float acc[MAXI][16];
+#pragma unroll
+        for (int s = 0; s < MAXI; ++s)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[s][e] = 0.f;
+        double v1 = 0.0, v2 = 0.0, v3 = 0.0;  // gh1, gd, gdq of vector item (o,k) = tid
+
+        for (int tile = blockIdx.x; tile < l.ntile_elbo; tile += gridDim.x) {
+            const int64_t s0 = l.own_lo + (int64_t)tile * l.TS;
+            const int64_t s1 = (s0 + l.TS < own_hi) ? s0 + l.TS : own_hi;
+            const int64_t tbase = s0 - l.kmax;
+            __syncthreads();
+            // ---- A: stage moments and window data
+            for (int idx = tid; idx < NS * 4 * TSYM; idx += NT) {
+                const int cq = idx / TSYM, ms = idx - cq * TSYM;
+                const int64_t m = tbase + ms;
+                s_mom[idx] = (m >= l.sym_lo && m < sym_hi) ? mom[(int64_t)cq * l.sym_cnt + (m - l.sym_lo)] : 0.f;
+            }
+            if (tid < TW) {
+                const int64_t t = tbase + tid;
+                const int64_t n = t * l.S + r;
+                const bool valid = (t < s1) && n >= 0 && n < l.W;
+                s_vl[tid] = valid ? 1.f : 0.f;
+                s_ow[tid] = (valid && t >= s0) ? 1.f : 0.f;
+                for (int o = 0; o < NS; ++o) {
+                    float v = 0.f;
+                    if (valid) {
+                        const int64_t loc = l.pre + n - l.y_lo;
+                        if (loc >= 0 && loc < l.y_len) v = y[(int64_t)o * l.y_len + loc];
+                    }
+                    s_yw[o * TW + tid] = v;
+                }
+            }
+            __syncthreads();
+            // ---- B: pass 1 -- u = H mu, tt = (H.H) v for this thread's rows; per-window partial scalars
+            for (int o = 0; o < NS; ++o) {
+                float pa = 0.f, pq = 0.f, ps = 0.f, psq = 0.f, pvs = 0.f;
+                const float* __restrict__ Ho = Hc + (size_t)o * LTp * LTp;
+                const float* __restrict__ HHo = HHc + (size_t)o * LTp * LTp;
+                for (int u = g; u < nb; u += NG) {
+                    const int k0 = u * 4;
+                    float uu[4] = {0.f, 0.f, 0.f, 0.f}, tt[4] = {0.f, 0.f, 0.f, 0.f};
+                    for (int c = 0; c < NS; ++c) {
+                        const float* mrow = s_mom + (c * 4 + 0) * TSYM + ts;
+                        const float* vrow = s_mom + (c * 4 + 1) * TSYM + ts;
+                        for (int kk = 0; kk < l.LE; ++kk) {
+                            const int j = c * l.LEp + kk;
+                            const float4 hv = *reinterpret_cast<const float4*>(Ho + (size_t)j * LTp + k0);
+                            const float4 hh = *reinterpret_cast<const float4*>(HHo + (size_t)j * LTp + k0);
+                            const float mj = mrow[kk], vj = vrow[kk];
+                            uu[0] = fmaf(hv.x, mj, uu[0]); uu[1] = fmaf(hv.y, mj, uu[1]);
+                            uu[2] = fmaf(hv.z, mj, uu[2]); uu[3] = fmaf(hv.w, mj, uu[3]);
+                            tt[0] = fmaf(hh.x, vj, tt[0]); tt[1] = fmaf(hh.y, vj, tt[1]);
+                            tt[2] = fmaf(hh.z, vj, tt[2]); tt[3] = fmaf(hh.w, vj, tt[3]);
+                        }
+                    }
+                    const int c = k0 / l.LEp, kk0 = k0 - c * l.LEp;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int k = k0 + i;
+                        const float* mb = s_mom + c * 4 * TSYM + ts + kk0 + i;
+                        const float mk = mb[0], vk = mb[TSYM], kp = mb[2 * TSYM], gm = mb[3 * TSYM];
+                        const float h1k = h1c[o * LTp + k], dk = dc[o * LTp + k], dqk = dqc[o * LTp + k];
+                        const float z = fmaf(2.f, uu[i], h1k);
+                        pa = fmaf(h1k, mk, pa);
+                        pq = fmaf(mk, uu[i], pq);
+                        ps = fmaf(vk, dk, ps);
+                        psq = fmaf(vk, dqk, psq);
+                        pvs += vk * z * z + 2.f * vk * tt[i] + 2.f * kp * dk * z + gm * dk * dk;
+                        s_z[(o * LTp + k) * TW + ts] = z;
+                        s_w[(o * LTp + k) * TW + ts] = 2.f * vk * z + 2.f * kp * dk;
+                        const float dv = z * z + 4.f * tt[i], dkp = 2.f * dk * z;
+                        if (o == 0) { s_Dv[k * TW + ts] = dv; s_Dk[k * TW + ts] = dkp; }
+                        else { s_Dv[k * TW + ts] += dv; s_Dk[k * TW + ts] += dkp; }
+                    }
+                }
+                float* rd = s_red + (o * 5 * NG + g) * TW + ts;
+                rd[0] = pa; rd[NG * TW] = pq; rd[2 * NG * TW] = ps; rd[3 * NG * TW] = psq; rd[4 * NG * TW] = pvs;
+            }
+            __syncthreads();
+            // ---- C: per-window scalars
+            if (tid < TW) {
+                const float vl = s_vl[tid];
+                float En = 0.f;
+                for (int o = 0; o < NS; ++o) {
+                    float q5[5];
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) {
+                        float s = 0.f;
+                        for (int gg = 0; gg < NG; ++gg) s += s_red[((o * 5 + q) * NG + gg) * TW + tid];
+                        q5[q] = s;
+                    }
+                    const float yv = s_yw[o * TW + tid];
+                    const float A = q5[0] + q5[1] + q5[2];
+                    const float e = A - yv;
+                    En += e * e + 2.f * yv * (q5[2] - q5[3]) + q5[4];
+                    s_ev[o * TW + tid] = vl * e;
+                    s_Av[o * TW + tid] = vl * A;
+                }
+                if (s_ow[tid] != 0.f) Eacc += (double)En;
+            }
+            __syncthreads();
+            // ---- D: pass 2 -- H w, per-(window, tap) gradients of the moments
+            for (int u = g; u < nb; u += NG) {
+                const int k0 = u * 4;
+                float dmu[4] = {0.f, 0.f, 0.f, 0.f}, dvx[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int o = 0; o < NS; ++o) {
+                    const float* __restrict__ Ho = Hc + (size_t)o * LTp * LTp;
+                    float hw[4] = {0.f, 0.f, 0.f, 0.f};
+                    for (int c = 0; c < NS; ++c)
+                        for (int kk = 0; kk < l.LE; ++kk) {
+                            const int j = c * l.LEp + kk;
+                            const float4 hv = *reinterpret_cast<const float4*>(Ho + (size_t)j * LTp + k0);
+                            const float wj = s_w[(o * LTp + j) * TW + ts];
+                            hw[0] = fmaf(hv.x, wj, hw[0]); hw[1] = fmaf(hv.y, wj, hw[1]);
+                            hw[2] = fmaf(hv.z, wj, hw[2]); hw[3] = fmaf(hv.w, wj, hw[3]);
+                        }
+                    const float e = s_ev[o * TW + ts], A = s_Av[o * TW + ts], yv = s_yw[o * TW + ts];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int k = k0 + i;
+                        dmu[i] += 2.f * e * s_z[(o * LTp + k) * TW + ts] + 2.f * hw[i];
+                        dvx[i] += 2.f * A * dc[o * LTp + k] - 2.f * yv * dqc[o * LTp + k];
+                    }
+                }
+                const float vl = s_vl[ts];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k = k0 + i;
+                    s_Dmu[k * TW + ts] = vl * dmu[i];
+                    s_Dv[k * TW + ts] = vl * (s_Dv[k * TW + ts] + dvx[i]);
+                    s_Dk[k * TW + ts] = vl * s_Dk[k * TW + ts];
+                }
+            }
+            __syncthreads();
+            // ---- E1: gather per-symbol gradients (symbol m = t + kk)
+            for (int idx = tid; idx < NS * l.TS; idx += NT) {
+                const int c = idx / l.TS, ml = idx - c * l.TS;
+                const int64_t m = s0 + ml;
+                if (m < s1) {
+                    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                    for (int kk = 0; kk < l.LE; ++kk) {
+                        const int k = c * l.LEp + kk;
+                        const int tsl = ml + l.kmax - kk;  // window slot of t = m - kk
+                        a0 += s_Dmu[k * TW + tsl];
+                        a1 += s_Dv[k * TW + tsl];
+                        a2 += s_Dk[k * TW + tsl];
+                        float dd = 0.f;
+                        for (int o = 0; o < NS; ++o) { const float d = dc[o * LTp + k]; dd = fmaf(d, d, dd); }
+                        a3 = fmaf(s_vl[tsl], dd, a3);
+                    }
+                    float* gp = gmom + (int64_t)c * 4 * l.sym_cnt + (m - l.sym_lo);
+                    if (r == 0) { gp[0] = a0; gp[l.sym_cnt] = a1; gp[2 * l.sym_cnt] = a2; gp[3 * l.sym_cnt] = a3; }
+                    else { gp[0] += a0; gp[l.sym_cnt] += a1; gp[2 * l.sym_cnt] += a2; gp[3 * l.sym_cnt] += a3; }
+                }
+            }
+            // ---- E2: parameter-gradient outer products over this tile's owned windows
+            if (active) {
+#pragma unroll
+                for (int s = 0; s < MAXI; ++s) {
+                    const int it = item0 + s * NT;
+                    if (it < l.nitems_elbo) {
+                        const bool isG = it < l.nG_elbo;
+                        const int itx = isG ? it : it - l.nG_elbo;
+                        const int o = isG ? itx / (nb * nb) : 0;
+                        const int r2 = itx - o * nb * nb;
+                        const int kb = r2 / nb, jb = r2 - kb * nb;
+                        const int ck = (kb * 4) / l.LEp, kk0 = kb * 4 - ck * l.LEp;
+                        const int cj = (jb * 4) / l.LEp, jj0 = jb * 4 - cj * l.LEp;
+                        const int q = isG ? 0 : 1;
+                        const float* rowm = s_mom + (ck * 4 + q) * TSYM + kk0;
+                        const float* colm = s_mom + (cj * 4 + q) * TSYM + jj0;
+                        for (int t = chunk; t < TW; t += nchunk) {
+                            const float wgt = s_ow[t];
+                            float xr[4], xc[4];
+                            if (isG) {
+                                const float e = s_ev[o * TW + t];
+#pragma unroll
+                                for (int i = 0; i < 4; ++i)
+                                    xr[i] = wgt * fmaf(e, rowm[t + i], s_w[(o * LTp + kb * 4 + i) * TW + t]);
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) xr[i] = wgt * rowm[t + i];
+                            }
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) xc[i] = colm[t + i];
+#pragma unroll
+                            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                                for (int b = 0; b < 4; ++b) acc[s][a * 4 + b] = fmaf(xr[a], xc[b], acc[s][a * 4 + b]);
+                        }
+                    }
+                }
+            }
+            // ---- E3: vector gradients (h1, diag, diag-of-mean), one (o,k) per thread
+            if (tid < NS * LTp) {
+                const int o = tid / LTp, k = tid - o * LTp;
+                const int c = k / l.LEp, kk = k - c * l.LEp;
+                const float dk = dc[o * LTp + k];
+                const float* mb = s_mom + c * 4 * TSYM + kk;
+                float f1 = 0.f, f2 = 0.f, f3 = 0.f;
+                for (int t = 0; t < TW; ++t) {
+                    const float wgt = s_ow[t];
+                    const float mk = mb[t], vk = mb[TSYM + t], kp = mb[2 * TSYM + t], gm = mb[3 * TSYM + t];
+                    const float e = s_ev[o * TW + t], A = s_Av[o * TW + t], yv = s_yw[o * TW + t];
+                    const float z = s_z[(o * LTp + k) * TW + t], w = s_w[(o * LTp + k) * TW + t];
+                    f1 += wgt * (2.f * e * mk + w);
+                    f2 += wgt * (2.f * A * vk + 2.f * kp * z + 2.f * gm * dk);
+                    f3 += wgt * (-2.f * yv * vk);
+                }
+                v1 += (double)f1; v2 += (double)f2; v3 += (double)f3;
+            }
+        }
+        // ---- flush this phase's partial sums
+        float* part = ws + l.o_part_elbo + (int64_t)blockIdx.x * l.rec_elbo + (size_t)r * rec_elbo_phase(l);
+        float* partG = part;
+        float* partP = part + NS * LTp * LTp;
+        float* partV = partP + LTp * LTp;
+        __syncthreads();
+        if (MAXI == 1 && l.nitems_elbo <= NT) {
+            for (int base = 0; base < nchunk; ++base) {
+                __syncthreads();
+                if (active && chunk == base)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) scratch[item0 * 16 + e] = (base == 0 ? 0.f : scratch[item0 * 16 + e]) + acc[0][e];
+            }
+            __syncthreads();
+            for (int idx = tid; idx < l.nitems_elbo * 16; idx += NT) {
+                const int it = idx / 16, e = idx - it * 16;
+                const bool isG = it < l.nG_elbo;
+                const int itx = isG ? it : it - l.nG_elbo;
+                const int o = isG ? itx / (nb * nb) : 0;
+                const int r2 = itx - o * nb * nb;
+                const int kb = r2 / nb, jb = r2 - kb * nb;
+                const int row = kb * 4 + e / 4, col = jb * 4 + (e & 3);
+                if (isG) partG[((size_t)o * LTp + row) * LTp + col] = 2.f * scratch[idx];
+                else partP[(size_t)row * LTp + col] = scratch[idx];
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < MAXI; ++s) {
+                const int it = item0 + s * NT;
+                if (it < l.nitems_elbo) {
+                    const bool isG = it < l.nG_elbo;
+                    const int itx = isG ? it : it - l.nG_elbo;
+                    const int o = isG ? itx / (nb * nb) : 0;
+                    const int r2 = itx - o * nb * nb;
+                    const int kb = r2 / nb, jb = r2 - kb * nb;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = kb * 4 + e / 4, col = jb * 4 + (e & 3);
+                        if (isG) partG[((size_t)o * LTp + row) * LTp + col] = 2.f * acc[s][e];
+                        else partP[(size_t)row * LTp + col] = acc[s][e];
+                    }
+                }
+            }
+        }
+        if (tid < NS * LTp) {
+            const int o = tid / LTp, k = tid - o * LTp;
+            partV[(o * 3 + 0) * LTp + k] = (float)v1;
+            partV[(o * 3 + 1) * LTp + k] = (float)v2;
+            partV[(o * 3 + 2) * LTp + k] = (float)v3;
+        }
+    }
+    const double s = block_sum_double(Eacc, dred);
+    if (tid == 0) reinterpret_cast<double*>(ws + l.o_Epart)[blockIdx.x] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// reductions, chain rules, optimiser
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_reduce_scalars(Lay l, const float* __restrict__ ws, double* __restrict__ scal) {
+    __shared__ double red[NT / 64];
+    const double* Ep = reinterpret_cast<const double*>(ws + l.o_Epart);
+    const double* Kp = reinterpret_cast<const double*>(ws + l.o_KLpart);
+    double e = 0.0, k = 0.0;
+    for (int i = threadIdx.x; i < l.nblk_elbo; i += NT) e += Ep[i];
+    for (int i = threadIdx.x; i < l.nblk_sym; i += NT) k += Kp[i];
+    const double es = block_sum_double(e, red);
+    const double ks = block_sum_double(k, red);
+    if (threadIdx.x == 0) { scal[V2VAE_SCAL_E] = es; scal[V2VAE_SCAL_KL] = ks; }
+}
+
+__global__ void k_finalize_scalars(double W, double* __restrict__ scal) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const double E = scal[V2VAE_SCAL_E];
+        scal[V2VAE_SCAL_LOSS] = scal[V2VAE_SCAL_KL] + W * log(E);
+        scal[V2VAE_SCAL_LAMBDA] = W / E;
+        scal[V2VAE_SCAL_W] = W;
+    }
+}
+
+__global__ __launch_bounds__(NT) void k_sum_records(const float* __restrict__ part, int rec, int nblk, float* __restrict__ tot) {
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= rec) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)part[(size_t)b * rec + i];
+    tot[i] = (float)s;
+}
+
+// dE/dHs[o][a][b] on original stacked taps from the per-phase compact totals
+__device__ __forceinline__ float GS_value(const Lay& l, const float* __restrict__ ws, int o, int a, int b) {
+    int ra, ka, rb, kb;
+    tap_to_compact(l, a, &ra, &ka);
+    tap_to_compact(l, b, &rb, &kb);
+    if (ra != rb) return 0.f;
+    const float* tot = ws + l.o_tot_elbo + (size_t)ra * rec_elbo_phase(l);
+    const float* G = tot;
+    const float* P = tot + l.ns * l.LTp * l.LTp;
+    const float* V = P + l.LTp * l.LTp;
+    const float Hv = ws[l.o_Hc + (((size_t)ra * l.ns + o) * l.LTp + ka) * l.LTp + kb];
+    float v = G[((size_t)o * l.LTp + ka) * l.LTp + kb] + 4.f * Hv * P[(size_t)ka * l.LTp + kb];
+    if (a == b) {
+        v += V[(o * 3 + 1) * l.LTp + ka];
+        if (l.mode != 0) v += V[(o * 3 + 2) * l.LTp + ka];
+    }
+    return v;
+}
+
+__device__ __forceinline__ float g1_value(const Lay& l, const float* __restrict__ ws, int o, int a, int which) {
+    int r, k;
+    tap_to_compact(l, a, &r, &k);
+    const float* V = ws + l.o_tot_elbo + (size_t)r * rec_elbo_phase(l) + l.ns * l.LTp * l.LTp + l.LTp * l.LTp;
+    return V[(o * 3 + which) * l.LTp + k];
+}
+
+__global__ __launch_bounds__(NT) void k_chain_channel(Lay l, const float* __restrict__ ws, const double* __restrict__ scal,
+                                                      const float* __restrict__ grad_scale, float* __restrict__ g_h1,
+                                                      float* __restrict__ g_h2) {
+    const float lam = (float)scal[V2VAE_SCAL_LAMBDA] * (grad_scale ? grad_scale[0] : 1.f);
+    const int L = l.L;
+    const int n1 = l.ns * L, n2 = l.ns * L * L;
+    for (int idx = blockIdx.x * NT + threadIdx.x; idx < n1 + n2; idx += gridDim.x * NT) {
+        if (idx < n1) {
+            if (!g_h1) continue;
+            float v;
+            if (l.mode == 0) v = g1_value(l, ws, 0, idx, 0);
+            else {
+                const int p = idx / L, i = idx - p * L;
+                v = (p == 0) ? g1_value(l, ws, 0, i, 0) + g1_value(l, ws, 1, L + i, 0)
+                             : -g1_value(l, ws, 0, L + i, 0) + g1_value(l, ws, 1, i, 0);
+            }
+            g_h1[idx] = lam * v;
+        } else {
+            if (!g_h2) continue;
+            const int e = idx - n1;
+            const int p = e / (L * L), rem = e - p * L * L;
+            const int i = rem / L, j = rem - i * L;
+            float v;
+            if (l.mode == 0) {
+                v = GS_value(l, ws, 0, i, j) + GS_value(l, ws, 0, j, i);
+                if (i == j) v += g1_value(l, ws, 0, i, 2);
+            } else {
+                const int ai = i, bi = L + i, aj = j, bj = L + j;
+                if (p == 0)
+                    v = (GS_value(l, ws, 0, ai, aj) - GS_value(l, ws, 0, bi, bj) + GS_value(l, ws, 1, ai, bj) + GS_value(l, ws, 1, bi, aj)) +
+                        (GS_value(l, ws, 0, aj, ai) - GS_value(l, ws, 0, bj, bi) + GS_value(l, ws, 1, aj, bi) + GS_value(l, ws, 1, bj, ai));
+                else
+                    v = (-GS_value(l, ws, 0, ai, bj) - GS_value(l, ws, 0, bi, aj) + GS_value(l, ws, 1, ai, aj) - GS_value(l, ws, 1, bi, bj)) +
+                        (-GS_value(l, ws, 0, aj, bi) - GS_value(l, ws, 0, bj, ai) + GS_value(l, ws, 1, aj, ai) - GS_value(l, ws, 1, bj, bi));
+            }
+            g_h2[e] = lam * v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT) void k_chain_equaliser(Lay l, const float* __restrict__ ws, float* __restrict__ g_k1,
+                                                        float* __restrict__ g_k2) {
+    const float* K2t = ws + l.o_tot_eq;
+    const float* K1t = K2t + (size_t)l.ns * l.LT2p * l.LT2p;
+    const int l1 = l.l1, l2 = l.l2, P = l.LT2p;
+    const int n1 = l.ns * l1, n2 = l.ns * l2 * l2;
+    auto K2 = [&](int o, int a, int b) { return K2t[((size_t)o * P + a) * P + b]; };
+    auto K1 = [&](int o, int c, int j) { return K1t[(o * l.ns + c) * l1 + j]; };
+    for (int idx = blockIdx.x * NT + threadIdx.x; idx < n1 + n2; idx += gridDim.x * NT) {
+        if (idx < n1) {
+            if (!g_k1) continue;
+            float v;
+            if (l.mode == 0) v = K1(0, 0, idx);
+            else {
+                const int p = idx / l1, j = idx - p * l1;
+                v = (p == 0) ? K1(0, 0, j) + K1(1, 1, j) : -K1(0, 1, j) + K1(1, 0, j);
+            }
+            g_k1[idx] = v;
+        } else {
+            if (!g_k2) continue;
+            const int e = idx - n1;
+            const int p = e / (l2 * l2), rem = e - p * l2 * l2;
+            const int i = rem / l2, j = rem - i * l2;
+            float v;
+            if (l.mode == 0) v = K2(0, i, j) + K2(0, j, i);
+            else {
+                const int ai = i, bi = l2 + i, aj = j, bj = l2 + j;
+                if (p == 0)
+                    v = (K2(0, ai, aj) - K2(0, bi, bj) + K2(1, ai, bj) + K2(1, bi, aj)) +
+                        (K2(0, aj, ai) - K2(0, bj, bi) + K2(1, aj, bi) + K2(1, bj, ai));
+                else
+                    v = (-K2(0, ai, bj) - K2(0, bi, aj) + K2(1, ai, aj) - K2(1, bi, bj)) +
+                        (-K2(0, aj, bi) - K2(0, bj, ai) + K2(1, aj, ai) - K2(1, bj, bi));
+            }
+            g_k2[e] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT) void k_copy(const float* __restrict__ src, float* __restrict__ dst, int n) {
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(NT) void k_adam(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                             float* __restrict__ v, float* __restrict__ vmax, float w1, float beta2,
+                                             float w2, float step_size, float bc2_sqrt, float eps,
+                                             const double* __restrict__ scal, float* __restrict__ noise_var,
+                                             float* __restrict__ loss_out) {
+    const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (i < n) {
+        const float gi = g[i];
+        const float mi = fmaf(w1, gi - m[i], m[i]);          // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = fmaf(w2 * gi, gi, v[i] * beta2);    // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        const float vm = fmaxf(vmax[i], vi);
+        const float denom = sqrtf(vm) / bc2_sqrt + eps;
+        m[i] = mi; v[i] = vi; vmax[i] = vm;
+        p[i] = p[i] - step_size * (mi / denom);
+    }
+    if (i == 0 && scal) {
+        if (noise_var) noise_var[0] = (float)(scal[V2VAE_SCAL_E] / scal[V2VAE_SCAL_W]);
+        if (loss_out) loss_out[0] = (float)scal[V2VAE_SCAL_LOSS];
+    }
+}
+
+static inline int launch_status() {
+    return hipGetLastError() == hipSuccess ? V2VAE_OK : V2VAE_ELAUNCH;
+}
+
+template <typename K>
+static inline int allow_lds(K kernel, int bytes) {
+    if (bytes <= 64 * 1024) return V2VAE_OK;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess
+               ? V2VAE_OK : V2VAE_ELAUNCH;
+}
+
+}  // namespace v2vae
+
+using namespace v2vae;
+
+extern "C" {
+
+const char* v2vae_version(void) { return "v2vae-hip 0.1 (gfx950)"; }
+
+int v2vae_check_problem(const v2vae_problem* p) {
+    Lay l;
+    return make_layout(p, &l);
+}
+
+size_t v2vae_workspace_bytes(const v2vae_problem* p) {
+    Lay l;
+    if (make_layout(p, &l) != V2VAE_OK) return 0;
+    return (size_t)l.total_floats * sizeof(float);
+}
+
+int64_t v2vae_ws_offset_moments(const v2vae_problem* p) {
+    Lay l;
+    return make_layout(p, &l) == V2VAE_OK ? l.o_mom : -1;
+}
+
+int64_t v2vae_ws_offset_gmoments(const v2vae_problem* p) {
+    Lay l;
+    return make_layout(p, &l) == V2VAE_OK ? l.o_gmom : -1;
+}
+
+int v2vae_prep_tables(const v2vae_problem* p, const float* h1, const float* h2, const float* k1, const float* k2,
+                      void* ws, void* stream) {
+    Lay l;
+    int rc = make_layout(p, &l);
+    if (rc) return rc;
+    // either group may be absent (NULL): channel tables need h1 and h2, equaliser tables k1 (and k2 if l2 > 0)
+    if (!ws || (!h1 && !k1) || (h1 && !h2) || (k1 && l.l2 > 0 && !k2)) return V2VAE_EINVAL;
+    hipLaunchKernelGGL(k_prep_tables, dim3(16), dim3(NT), 0, (hipStream_t)stream, l, h1, h2, k1, k2, (float*)ws);
+    return launch_status();
+}
+
+int v2vae_eq_fwd(const v2vae_problem* p, const float* y, const void* ws, float* xhat, void* stream) {
+    Lay l;
+    int rc = make_layout(p, &l);
+    if (rc) return rc;
+    if (!y || !ws || !xhat) return V2VAE_EINVAL;
+    rc = allow_lds(k_eq_fwd, l.lds_eq);
+    if (rc) return rc;
+    const int nblk = (int)((l.sym_cnt + EQ_TB - 1) / EQ_TB);
+    hipLaunchKernelGGL(k_eq_fwd, dim3(nblk), dim3(NT), l.lds_eq, (hipStream_t)stream, l, y, (const float*)ws, xhat);
+    return launch_status();
+}
+
+int v2vae_demap_moments(const v2vae_problem* p, const float* xhat, const float* levels, const float* prior,
+                        const float* scaling, const float* noise_var, void* ws, float* q_out, void* stream) {
+    Lay l;
+    int rc = make_layout(p, &l);
+    if (rc) return rc;
+    if (!xhat || !levels || !prior || !scaling || !noise_var || !ws) return V2VAE_EINVAL;
+    hipLaunchKernelGGL(k_demap_moments, dim3(l.nblk_sym), dim3(NT), 0, (hipStream_t)stream, l, xhat, levels, prior,
+                       scaling, noise_var, (float*)ws, q_out);
+    return launch_status();
+}
+
+int v2vae_decide(const v2vae_problem* p, const float* xhat, const float* levels, const float* scaling,
+                 const float* noise_var, int32_t* dec, void* stream) {
+    Lay l;
+    int rc = make_layout(p, &l);
+    if (rc) return rc;
+    if (!xhat || !levels || !scaling || !noise_var || !dec) return V2VAE_EINVAL;
+    hipLaunchKernelGGL(k_decide, dim3(l.nblk_sym), dim3(NT), 0, (hipStream_t)stream, l, xhat, levels, scaling, noise_var, dec);
+    return launch_status();
+}
+
+int v2vae_elbo_fused(const v2vae_problem* p, const float* y, void* ws, void* stream) {
+    Lay l;
+    int rc = make_layout(p, &l);
+    if (rc) return rc;
+    if (!y || !ws) return V2VAE_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+#define V2VAE_LAUNCH_ELBO(M)                                                                              \
+    do {                                                                                                  \
+        rc = allow_lds(k_elbo<M>, l.lds_elbo);                                                            \
+        if (rc) return rc;                                                                                \
+        hipLaunchKernelGGL(k_elbo<M>, dim3(l.nblk_elbo), dim3(NT), l.lds_elbo, st, l, y, (float*)ws);     \
+    } while (0)
+    if (l.maxi_elbo == 1) V2VAE_LAUNCH_ELBO(1);
+    else if (l.maxi_elbo == 2) V2VAE_LAUNCH_ELBO(2);
+    else V2VAE_LAUNCH_ELBO(4);
+#undef V2VAE_LAUNCH_ELBO
+    return launch_status();
+}
+
+int v2vae_reduce_scalars(const v2vae_problem* p, const void* ws, double* scal, void* stream) {
+    Lay l;
+    int rc = make_layout(p, &l);
+    if (rc) return rc;
+    if (!ws || !scal) return V2VAE_EINVAL;
+    hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(NT), 0, (hipStream_t)stream, l, (const float*)ws, scal);
+    return launch_status();
+}
+
+int v2vae_finalize_scalars(const v2vae_problem* p, double* scal, void* stream) {
+    Lay l;
+    int rc = make_layout(p, &l);
+    if (rc) return rc;
+    if (!scal) return V2VAE_EINVAL;
+    hipLaunchKernelGGL(k_finalize_scalars, dim3(1), dim3(64), 0, (hipStream_t)stream, (double)l.W, scal);
+    return launch_status();
+}
+
+int v2vae_sym_bwd(const v2vae_problem* p, const float* xhat, const float* levels, const float* prior,
+                  const float* scaling, const float* noise_var, const double* scal, const float* grad_scale,
+                  void* ws, float* gxhat, void* stream) {
+    Lay l;
+    int rc = make_layout(p, &l);
+    if (rc) return rc;
+    if (!xhat || !levels || !prior || !scaling || !noise_var || !scal || !ws || !gxhat) return V2VAE_EINVAL;
+    hipLaunchKernelGGL(k_sym_bwd, dim3(l.nblk_sym), dim3(NT), 0, (hipStream_t)stream, l, xhat, levels, prior, scaling,
+                       noise_var, scal, grad_scale, (float*)ws, gxhat);
+    return launch_status();
+}
+
+int v2vae_eq_bwd(const v2vae_problem* p, const float* y, const float* gxhat, void* ws, void* stream) {
+    Lay l;
+    int rc = make_layout(p, &l);
+    if (rc) return rc;
+    if (!y || !gxhat || !ws) return V2VAE_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+#define V2VAE_LAUNCH_EQB(M)                                                                                   \
+    do {                                                                                                      \
+        rc = allow_lds(k_eq_bwd<M>, l.lds_eq);                                                                \
+        if (rc) return rc;                                                                                    \
+        hipLaunchKernelGGL(k_eq_bwd<M>, dim3(l.nblk_eq), dim3(NT), l.lds_eq, st, l, y, gxhat, (float*)ws);    \
+    } while (0)
+    if (l.maxi_eq == 1) V2VAE_LAUNCH_EQB(1);
+    else if (l.maxi_eq == 2) V2VAE_LAUNCH_EQB(2);
+    else if (l.maxi_eq <= 4) V2VAE_LAUNCH_EQB(4);
+    else V2VAE_LAUNCH_EQB(10);
+#undef V2VAE_LAUNCH_EQB
+    return launch_status();
+}
+
+int v2vae_finish_grads(const v2vae_problem* p, void* ws, const double* scal, const float* grad_scale, int which,
+                       float* g_h1, float* g_h2, float* g_k1, float* g_k2, float* g_scaling, void* stream) {
+    Lay l;
+    int rc = make_layout(p, &l);
+    if (rc) return rc;
+    if (!ws || !scal) return V2VAE_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    float* w = (float*)ws;
+    if (which & 1) {
+        hipLaunchKernelGGL(k_sum_records, dim3((l.rec_elbo + NT - 1) / NT), dim3(NT), 0, st, w + l.o_part_elbo, l.rec_elbo,
+                           l.nblk_elbo, w + l.o_tot_elbo);
+        const int n = l.ns * l.L + l.ns * l.L * l.L;
+        hipLaunchKernelGGL(k_chain_channel, dim3((n + NT - 1) / NT), dim3(NT), 0, st, l, (const float*)w, scal, grad_scale, g_h1, g_h2);
+    }
+    if (which & 2) {
+        hipLaunchKernelGGL(k_sum_records, dim3((l.rec_sym + NT - 1) / NT), dim3(NT), 0, st, w + l.o_part_sym, l.rec_sym,
+                           l.nblk_sym, w + l.o_tot_sym);
+        if (g_scaling)
+            hipLaunchKernelGGL(k_copy, dim3((l.rec_sym + NT - 1) / NT), dim3(NT), 0, st, (const float*)(w + l.o_tot_sym), g_scaling, l.rec_sym);
+    }
+    if (which & 4) {
+        hipLaunchKernelGGL(k_sum_records, dim3((l.rec_eq + NT - 1) / NT), dim3(NT), 0, st, w + l.o_part_eq, l.rec_eq,
+                           l.nblk_eq, w + l.o_tot_eq);
+        const int n = l.ns * l.l1 + l.ns * l.l2 * l.l2;
+        hipLaunchKernelGGL(k_chain_equaliser, dim3((n + NT - 1) / NT), dim3(NT), 0, st, l, (const float*)w, g_k1, g_k2);
+    }
+    return launch_status();
+}
+
+int v2vae_adam_amsgrad(int64_t n, float* params, const float* grads, float* m, float* v, float* vmax, float lr,
+                       float beta1, float beta2, float eps, int64_t step, const double* scal, float* noise_var,
+                       float* loss_out, void* stream) {
+    if (n < 1 || !params || !grads || !m || !v || !vmax || step < 1) return V2VAE_EINVAL;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    const float w1 = (float)(1.0 - (double)beta1);
+    const float w2 = (float)(1.0 - (double)beta2);
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, n, params, grads, m, v,
+                       vmax, w1, beta2, w2, step_size, bc2_sqrt, eps, scal, noise_var, loss_out);
+    return launch_status();
+}
+
+void v2vae_pack_sizes(const v2vae_problem* p, int64_t out[5]) {
+    out[0] = (int64_t)p->ns * p->L;
+    out[1] = (int64_t)p->ns * p->L * p->L;
+    out[2] = (int64_t)p->ns * p->l1;
+    out[3] = (int64_t)p->ns * p->l2 * p->l2;
+    out[4] = (int64_t)p->ns * p->C;
+}
+
+int v2vae_train_step(const v2vae_problem* p, const v2vae_train_args* a, void* stream) {
+    if (!p || !a) return V2VAE_EINVAL;
+    int64_t n[5];
+    v2vae_pack_sizes(p, n);
+    float* h1 = a->params;
+    float* h2 = h1 + n[0];
+    float* k1 = h2 + n[1];
+    float* k2 = k1 + n[2];
+    float* sc = k2 + n[3];
+    float* g = a->grads;
+    int rc;
+    if ((rc = v2vae_prep_tables(p, h1, h2, k1, n[3] ? k2 : nullptr, a->ws, stream))) return rc;
+    if ((rc = v2vae_eq_fwd(p, a->y, a->ws, a->xhat, stream))) return rc;
+    if ((rc = v2vae_demap_moments(p, a->xhat, a->levels, a->prior, sc, a->noise_var, a->ws, nullptr, stream))) return rc;
+    if ((rc = v2vae_elbo_fused(p, a->y, a->ws, stream))) return rc;
+    if ((rc = v2vae_reduce_scalars(p, a->ws, a->scal, stream))) return rc;
+    if ((rc = v2vae_finalize_scalars(p, a->scal, stream))) return rc;
+    if ((rc = v2vae_sym_bwd(p, a->xhat, a->levels, a->prior, sc, a->noise_var, a->scal, nullptr, a->ws, a->gxhat, stream))) return rc;
+    if ((rc = v2vae_eq_bwd(p, a->y, a->gxhat, a->ws, stream))) return rc;
+    if ((rc = v2vae_finish_grads(p, a->ws, a->scal, nullptr, 7, g, g + n[0], g + n[0] + n[1], n[3] ? g + n[0] + n[1] + n[2] : nullptr,
+                                 g + n[0] + n[1] + n[2] + n[3], stream))) return rc;
+    const int64_t nadam = n[0] + n[1] + n[2] + n[3] + (a->learn_scaling ? n[4] : 0);
+    return v2vae_adam_amsgrad(nadam, a->params, g, a->adam_m, a->adam_v, a->adam_vmax, a->lr, a->beta1, a->beta2, a->eps,
+                              a->step, a->scal, a->adaptive_noise ? a->noise_var : nullptr, a->loss_out, stream);
+}
+
+}  // extern "C"

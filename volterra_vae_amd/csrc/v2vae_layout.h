@@ -1,0 +1,53 @@
+// Problem geometry shared by the host entry points and the device kernels.
+// Everything a kernel needs besides pointers travels in one `Lay` value (kernel argument).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/v2vae_hip.h"
+
+#if defined(__HIPCC__)
+#define V2VAE_HD __host__ __device__
+#else
+#define V2VAE_HD
+#endif
+
+namespace v2vae {
+
+constexpr int NT = 256;         // threads per workgroup (4 waves of 64)
+constexpr int MAX_C = 16;       // amplitude levels per stream
+constexpr int EQ_TB = 256;      // symbols per equaliser tile
+constexpr int LDS_BUDGET = 150 * 1024;
+constexpr int SCRATCH_F = 4096; // floats of LDS scratch for cross-chunk reductions
+constexpr int MAX_BLOCKS = 512; // persistent workgroups per kernel (2 per CU)
+
+struct Lay {
+    int ns, mode, S, l1, pad1, l2, L, C;
+    int64_t n_glob, y_lo, y_len, sym_lo, sym_cnt, own_lo, own_cnt;
+    int pre;                 // (L-1)/2: y' = y[pre + n]
+    int64_t b_glob, W, kl_lo, kl_hi;
+    int kmax, LE, LEp, LTp;  // compact channel taps per phase
+    int p2, LT2, LT2p;       // stacked equaliser lags
+    int hl, hr, tile_len;    // equaliser sample tile: [b0*S - hl, b0*S + EQ_TB*S + hr)
+    // ELBO tiling
+    int TWIN, TS, NG, TSYM, ntile_elbo, nblk_elbo, nitems_elbo, nG_elbo, nchunk_elbo, maxi_elbo;
+    int lds_elbo;            // bytes
+    // equaliser backward tiling
+    int ntile_eq, nblk_eq, nitems_eq, nchunk_eq, maxi_eq, nk1;
+    int lds_eq;              // bytes (forward and backward use the same carve)
+    int nblk_sym;
+    // record sizes of the per-workgroup partial sums (floats)
+    int rec_elbo, rec_eq, rec_sym;
+    // workspace offsets in floats
+    int64_t o_eqK1, o_eqK2, o_h1c, o_Hc, o_HHc, o_dc, o_dqc, o_mom, o_gmom;
+    int64_t o_part_elbo, o_part_eq, o_part_sym, o_tot_elbo, o_tot_eq, o_tot_sym;
+    int64_t o_Epart, o_KLpart;  // doubles, offsets still in floats (8-byte aligned)
+    int64_t total_floats;
+};
+
+// offsets inside one ELBO record: [S][ G: ns*LTp*LTp | P: LTp*LTp | vec: ns*3*LTp ]
+V2VAE_HD inline int rec_elbo_phase(const Lay& l) { return l.ns * l.LTp * l.LTp + l.LTp * l.LTp + l.ns * 3 * l.LTp; }
+
+int make_layout(const v2vae_problem* p, Lay* out);
+
+}  // namespace v2vae

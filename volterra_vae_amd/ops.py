@@ -1,0 +1,199 @@
+"""Thin torch layer over the C ABI: tensors in, kernels enqueued on torch's current HIP stream.
+
+`Plan` binds one problem geometry (sizes + which slice of the batch this rank owns) to its
+workspace; the autograd Functions below make the equaliser and the ELBO differentiable torch
+ops whose forward and backward are the hand-written kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import Problem, TrainArgs, check, lib
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_gpu_f32(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU: the V2VAE hot path has no CPU implementation")
+    if t.dtype != torch.float32:
+        raise NotImplementedError(f"{name}: the HIP kernels compute in float32 (got {t.dtype})")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+
+
+class Plan:
+    """Geometry + workspace for one (batch length, model shape, owned slice) combination."""
+
+    def __init__(self, *, ns, sps, l1, pad1, l2, L, C_levels, n_glob, device,
+                 y_lo=0, y_len=None, sym_lo=0, sym_cnt=None, own_lo=None, own_cnt=None):
+        b_glob = n_glob // sps
+        p = Problem()
+        p.ns, p.mode, p.sps, p.l1, p.pad1, p.l2, p.L, p.C = ns, (0 if ns == 1 else 1), sps, l1, pad1, l2, L, C_levels
+        p.n_glob, p.y_lo = n_glob, y_lo
+        p.y_len = n_glob if y_len is None else y_len
+        p.sym_lo = sym_lo
+        p.sym_cnt = b_glob if sym_cnt is None else sym_cnt
+        p.own_lo = p.sym_lo if own_lo is None else own_lo
+        p.own_cnt = p.sym_cnt if own_cnt is None else own_cnt
+        check(lib.v2vae_check_problem(C.byref(p)), "v2vae_check_problem")
+        self.p = p
+        self.device = device
+        nbytes = lib.v2vae_workspace_bytes(C.byref(p))
+        self.ws = torch.zeros((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        self.scal = torch.zeros(_lib.SCAL_COUNT, dtype=torch.float64, device=device)
+        self.gxhat = torch.zeros((ns, p.sym_cnt), dtype=torch.float32, device=device)
+        self.sizes = _lib.pack_sizes(p)
+        self.W = n_glob - L + 1
+
+    # --- individual stages ---------------------------------------------------------------
+    def prep_tables(self, h1=None, h2=None, k1=None, k2=None):
+        check(lib.v2vae_prep_tables(C.byref(self.p), _ptr(h1), _ptr(h2), _ptr(k1), _ptr(k2), _ptr(self.ws), _stream()),
+              "v2vae_prep_tables")
+
+    def eq_fwd(self, y, xhat):
+        check(lib.v2vae_eq_fwd(C.byref(self.p), _ptr(y), _ptr(self.ws), _ptr(xhat), _stream()), "v2vae_eq_fwd")
+
+    def demap_moments(self, xhat, levels, prior, scaling, noise_var, q_out=None):
+        check(lib.v2vae_demap_moments(C.byref(self.p), _ptr(xhat), _ptr(levels), _ptr(prior), _ptr(scaling), _ptr(noise_var),
+                                      _ptr(self.ws), _ptr(q_out), _stream()), "v2vae_demap_moments")
+
+    def elbo_fused(self, y):
+        check(lib.v2vae_elbo_fused(C.byref(self.p), _ptr(y), _ptr(self.ws), _stream()), "v2vae_elbo_fused")
+
+    def reduce_scalars(self):
+        check(lib.v2vae_reduce_scalars(C.byref(self.p), _ptr(self.ws), _ptr(self.scal), _stream()), "v2vae_reduce_scalars")
+
+    def finalize_scalars(self):
+        check(lib.v2vae_finalize_scalars(C.byref(self.p), _ptr(self.scal), _stream()), "v2vae_finalize_scalars")
+
+    def sym_bwd(self, xhat, levels, prior, scaling, noise_var, grad_scale=None, gxhat=None):
+        gx = self.gxhat if gxhat is None else gxhat
+        check(lib.v2vae_sym_bwd(C.byref(self.p), _ptr(xhat), _ptr(levels), _ptr(prior), _ptr(scaling), _ptr(noise_var),
+                                _ptr(self.scal), _ptr(grad_scale), _ptr(self.ws), _ptr(gx), _stream()), "v2vae_sym_bwd")
+        return gx
+
+    def eq_bwd(self, y, gxhat):
+        check(lib.v2vae_eq_bwd(C.byref(self.p), _ptr(y), _ptr(gxhat), _ptr(self.ws), _stream()), "v2vae_eq_bwd")
+
+    def finish_grads(self, which, g_h1=None, g_h2=None, g_k1=None, g_k2=None, g_scaling=None, grad_scale=None):
+        check(lib.v2vae_finish_grads(C.byref(self.p), _ptr(self.ws), _ptr(self.scal), _ptr(grad_scale), which,
+                                     _ptr(g_h1), _ptr(g_h2), _ptr(g_k1), _ptr(g_k2), _ptr(g_scaling), _stream()),
+              "v2vae_finish_grads")
+
+    def decide(self, xhat, levels, scaling, noise_var):
+        dec = torch.empty((self.p.ns, self.p.sym_cnt), dtype=torch.int32, device=self.device)
+        check(lib.v2vae_decide(C.byref(self.p), _ptr(xhat), _ptr(levels), _ptr(scaling), _ptr(noise_var), _ptr(dec), _stream()),
+              "v2vae_decide")
+        return dec
+
+    def moments_view(self):
+        off = lib.v2vae_ws_offset_moments(C.byref(self.p))
+        n = self.p.ns * 4 * self.p.sym_cnt
+        return self.ws[off:off + n].view(self.p.ns, 4, self.p.sym_cnt)
+
+    def gmoments_view(self):
+        off = lib.v2vae_ws_offset_gmoments(C.byref(self.p))
+        n = self.p.ns * 4 * self.p.sym_cnt
+        return self.ws[off:off + n].view(self.p.ns, 4, self.p.sym_cnt)
+
+    # --- whole fused step ------------------------------------------------------------------
+    def train_step(self, *, y, levels, prior, params, grads, adam_m, adam_v, adam_vmax, noise_var, xhat, loss_out,
+                   lr, step, beta1=0.9, beta2=0.999, eps=1e-8, learn_scaling=True, adaptive_noise=True):
+        a = TrainArgs()
+        a.y, a.levels, a.prior = y.data_ptr(), levels.data_ptr(), prior.data_ptr()
+        a.params, a.grads = params.data_ptr(), grads.data_ptr()
+        a.adam_m, a.adam_v, a.adam_vmax = adam_m.data_ptr(), adam_v.data_ptr(), adam_vmax.data_ptr()
+        a.noise_var, a.ws, a.scal = noise_var.data_ptr(), self.ws.data_ptr(), self.scal.data_ptr()
+        a.xhat, a.gxhat = xhat.data_ptr(), self.gxhat.data_ptr()
+        a.loss_out = 0 if loss_out is None else loss_out.data_ptr()
+        a.lr, a.beta1, a.beta2, a.eps, a.step = lr, beta1, beta2, eps, step
+        a.learn_scaling, a.adaptive_noise = int(learn_scaling), int(adaptive_noise)
+        check(lib.v2vae_train_step(C.byref(self.p), C.byref(a), _stream()), "v2vae_train_step")
+
+
+def adam_amsgrad_(params, grads, m, v, vmax, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, scal=None, noise_var=None,
+                  loss_out=None, n=None):
+    n = params.numel() if n is None else n
+    check(lib.v2vae_adam_amsgrad(n, _ptr(params), _ptr(grads), _ptr(m), _ptr(v), _ptr(vmax), lr, beta1, beta2, eps, step,
+                                 _ptr(scal), _ptr(noise_var), _ptr(loss_out), _stream()), "v2vae_adam_amsgrad")
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd ops
+# ------------------------------------------------------------------------------------------------
+class EqualiserFn(torch.autograd.Function):
+    """xhat = equaliser(y; k1, k2) through v2vae_eq_fwd / v2vae_eq_bwd.  y: [ns, N] (no gradient)."""
+
+    @staticmethod
+    def forward(ctx, plan: Plan, y, k1, k2):
+        _require_gpu_f32(y, "y")
+        k1c = k1.detach().contiguous()
+        k2c = None if k2 is None else k2.detach().contiguous()
+        plan.prep_tables(k1=k1c, k2=k2c)
+        xhat = torch.empty((plan.p.ns, plan.p.sym_cnt), dtype=torch.float32, device=y.device)
+        plan.eq_fwd(y, xhat)
+        ctx.plan = plan
+        ctx.save_for_backward(y)
+        ctx.k_shapes = (k1.shape, None if k2 is None else k2.shape)
+        return xhat
+
+    @staticmethod
+    def backward(ctx, gx):
+        plan = ctx.plan
+        (y,) = ctx.saved_tensors
+        gx = gx.contiguous()
+        plan.eq_bwd(y, gx)
+        s1, s2 = ctx.k_shapes
+        g_k1 = torch.empty(s1, dtype=torch.float32, device=y.device)
+        g_k2 = None if s2 is None else torch.empty(s2, dtype=torch.float32, device=y.device)
+        plan.finish_grads(4, g_k1=g_k1, g_k2=g_k2)
+        return None, None, g_k1, g_k2
+
+
+class ElboLossFn(torch.autograd.Function):
+    """loss = KL + W log E through the fused ELBO kernels.  Returns (loss, E); E carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, plan: Plan, xhat, y, h1, h2, scaling, noise_var, levels, prior):
+        _require_gpu_f32(y, "y")
+        xh = xhat.detach().contiguous()
+        h1c, h2c, scc = h1.detach().contiguous(), h2.detach().contiguous(), scaling.detach().contiguous()
+        nv = noise_var.detach().clone()
+        plan.prep_tables(h1=h1c, h2=h2c)
+        plan.demap_moments(xh, levels, prior, scc, nv)
+        plan.elbo_fused(y)
+        plan.reduce_scalars()
+        plan.finalize_scalars()
+        ctx.plan = plan
+        ctx.save_for_backward(xh, scc, nv, levels, prior)
+        ctx.shapes = (h1.shape, h2.shape, scaling.shape, xhat.shape)
+        sc = plan.scal.clone()
+        loss = sc[_lib.SCAL_LOSS].to(torch.float32)
+        E = sc[_lib.SCAL_E].to(torch.float32)
+        ctx.mark_non_differentiable(E)
+        return loss, E
+
+    @staticmethod
+    def backward(ctx, gloss, _gE):
+        plan = ctx.plan
+        xh, scc, nv, levels, prior = ctx.saved_tensors
+        gs = gloss.detach().to(torch.float32).reshape(1).contiguous()
+        gx = torch.empty_like(xh)
+        plan.sym_bwd(xh, levels, prior, scc, nv, grad_scale=gs, gxhat=gx)
+        s1, s2, s3, sx = ctx.shapes
+        g_h1 = torch.empty(s1, dtype=torch.float32, device=xh.device)
+        g_h2 = torch.empty(s2, dtype=torch.float32, device=xh.device)
+        g_sc = torch.empty(s3, dtype=torch.float32, device=xh.device)
+        plan.finish_grads(3, g_h1=g_h1, g_h2=g_h2, g_scaling=g_sc, grad_scale=gs)
+        return None, gx.view(sx), None, g_h1, g_h2, g_sc, None, None, None
