@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""V2VAE train-step throughput on MI355X.
+
+A step = forward + ELBO + backward + Adam-AMSGrad update of one batch, inputs resident in HBM.
+Workload at 1 GPU: complex 16-QAM V2VAE, channel memory L=25, equaliser l1=l2=25, 2 samples per
+symbol, one batch of 2^22 symbols (BASELINE.json configs[1]; S, l1, l2 and "one batch = the whole
+block" are this build's stated assumptions, the baseline file does not fix them).  With N GPUs the
+batch grows to N * 2^22 symbols, halo-sharded by contiguous blocks (weak scaling), with two tiny
+RCCL all-reduces per step.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_TFLOPS = 157.3  # MI355X dense fp32 (vector == f32 MFMA) peak
+
+
+def algorithmic_flops_per_symbol(L, S, l1, l2, cplx):
+    """Per-symbol algorithmic flops of each compute kernel and of the whole step (real arithmetic;
+    complex arithmetic counts 4 real multiply-adds per complex one)."""
+    c = 4 if cplx else 1
+    return {
+        "eq_fwd": c * (2 * l1 + 2 * l2 * l2 + 2 * l2),
+        "eq_bwd": c * (2 * l1 + 2 * l2 * l2),
+        "elbo_fused": c * 12 * L * L / S,
+    }
+
+
+def cpu_baseline(L, S, l1, l2, order, budget_s=12.0):
+    import torch
+    from oracle import v2vae_oracle as orc
+    from volterra_vae_amd.synth import nonlinear_isi_range, qam_constellation
+    nthreads = torch.get_num_threads()
+    B = 1 << 15
+    rx, _ = nonlinear_isi_range(1234, qam_constellation(order), S, 16.0, 0, B, B)
+    y = torch.from_numpy(np.stack((rx.real, rx.imag))).to(torch.float32)
+    port = orc.ComplexV2VAEPort(L, l1, l2, order, S, 5e-3, 10 ** -1.6, dtype=torch.float32)
+    port.step(y)  # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        port.step(y)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 50:
+            break
+    return {"value": n * B / el, "unit": "symbols/s", "cores": nthreads, "kind": "port",
+            "sample": f"{n} train steps of one {B}-symbol batch (same model shape, fp32, torch CPU oracle, window form)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2-symbols", type=int, default=22, help="symbols per GPU = 2^this")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from volterra_vae_amd.distributed import ShardedTrainer, shard_ranges
+    from volterra_vae_amd.ops import Plan
+    from volterra_vae_amd.synth import nonlinear_isi_range, qam_constellation
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    L, S, l1, l2, order = 25, 2, 25, 25, 16
+    M = int(round(np.sqrt(order)))
+    b_per_gpu = 1 << args.log2_symbols
+    b_glob = b_per_gpu * world
+    n_glob = b_glob * S
+    sr = shard_ranges(rank, world, n_glob, S, L, l1, l1 // 2, l2)
+    plan = Plan(ns=2, sps=S, l1=l1, pad1=l1 // 2, l2=l2, L=L, C_levels=M, n_glob=n_glob, device=dev,
+                y_lo=sr.y_lo, y_len=sr.y_len, sym_lo=sr.sym_lo, sym_cnt=sr.sym_cnt, own_lo=sr.own_lo, own_cnt=sr.own_cnt)
+
+    # synthetic nonlinear-ISI input for this rank's sample range (identical across ranks where ranges overlap)
+    assert sr.y_lo % S == 0 or True
+    s_lo, s_hi = sr.y_lo // S, -(-(sr.y_lo + sr.y_len) // S)
+    rx, _ = nonlinear_isi_range(20250321, qam_constellation(order), S, 16.0, s_lo, s_hi, b_glob)
+    rx = rx[sr.y_lo - s_lo * S: sr.y_lo - s_lo * S + sr.y_len]
+    y = torch.from_numpy(np.stack((rx.real, rx.imag))).to(torch.float32).to(dev).contiguous()
+
+    n = plan.sizes
+    params = torch.zeros(sum(n), dtype=torch.float32, device=dev)
+    params[L // 2] = 1.0                              # h1 = dirac (Re plane)
+    params[n[0] + n[1] + l1 // 2] = 1.0               # k1 = dirac (Re plane)
+    params[n[0] + n[1] + n[2] + n[3]:] = 1.0          # noise scaling
+    grads, am, av, avm = (torch.zeros_like(params) for _ in range(4))
+    lv = torch.arange(-(M - 1), M, 2, dtype=torch.float32, device=dev)
+    levels = torch.stack((lv, lv)).contiguous()
+    prior = torch.full_like(levels, 1.0 / M)
+    noise_var = torch.tensor([10 ** -1.6], dtype=torch.float32, device=dev)
+    xhat = torch.empty((2, sr.sym_cnt), dtype=torch.float32, device=dev)
+    loss = torch.zeros(1, dtype=torch.float32, device=dev)
+    trainer = ShardedTrainer(plan) if world > 1 else None
+    kw = dict(y=y, levels=levels, prior=prior, params=params, grads=grads, adam_m=am, adam_v=av, adam_vmax=avm,
+              noise_var=noise_var, xhat=xhat, loss_out=loss, lr=5e-3)
+
+    def one_step(i):
+        if trainer is None:
+            plan.train_step(step=i, **kw)
+        else:
+            trainer.step(step=i, **kw)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(i + 1)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i + 1)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    final_loss = float(loss)
+    if not np.isfinite(final_loss):
+        raise SystemExit(f"non-finite loss {final_loss}")
+
+    # per-kernel durations with events on the launch stream (torch's current stream), stage by stage
+    o = np.cumsum([0] + n)
+    h1, h2, k1, k2, sc = (params[o[i]:o[i + 1]] for i in range(5))
+    stages = {
+        "prep_tables": lambda: plan.prep_tables(h1, h2, k1, k2),
+        "eq_fwd": lambda: plan.eq_fwd(y, xhat),
+        "demap_moments": lambda: plan.demap_moments(xhat, levels, prior, sc, noise_var),
+        "elbo_fused": lambda: plan.elbo_fused(y),
+        "reduce_scalars": lambda: (plan.reduce_scalars(), plan.finalize_scalars()),
+        "sym_bwd": lambda: plan.sym_bwd(xhat, levels, prior, sc, noise_var),
+        "eq_bwd": lambda: plan.eq_bwd(y, plan.gxhat),
+        "finish_grads": lambda: plan.finish_grads(7, grads[o[0]:o[1]], grads[o[1]:o[2]], grads[o[2]:o[3]], grads[o[3]:o[4]], grads[o[4]:o[5]]),
+    }
+    kernel_ms = {k: 0.0 for k in stages}
+    reps = max(3, min(args.steps, 10))
+    for _ in range(reps):
+        for name, fn in stages.items():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            e1.synchronize()
+            kernel_ms[name] += e0.elapsed_time(e1) / reps
+    fence()
+
+    if rank == 0:
+        fl = algorithmic_flops_per_symbol(L, S, l1, l2, True)
+        dom = max(fl, key=lambda k: kernel_ms[k])
+        achieved = fl[dom] * sr.own_cnt / (kernel_ms[dom] * 1e-3) / 1e12
+        step_flops = sum(fl.values()) * b_glob
+        ms_per_step = elapsed / args.steps * 1e3
+        out = {
+            "metric": "V2VAE train-step symbols/sec (fwd+bwd) at 1/2/4/8 MI355X; % of HBM/MFMA roofline",
+            "value": b_glob * args.steps / elapsed, "unit": "symbols/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"complex 16-QAM V2VAE train step, L=25, l1=l2=25, sps=2, one batch of {world}x2^{args.log2_symbols} symbols, "
+                                   "Adam-AMSGrad, random-init (dirac) kernels, synthetic Wiener-Hammerstein ISI at 16 dB",
+                       "symbols_per_gpu": b_per_gpu, "parallelism": f"halo-sharded dp{world}" if world > 1 else "single GPU"},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                         "algorithmic_flops_per_symbol": fl[dom], "kernel_ms": kernel_ms[dom],
+                         "whole_step_frac": step_flops / world / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_TFLOPS},
+            "kernel_ms": kernel_ms, "final_loss": final_loss,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(L, S, l1, l2, order)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -165,6 +165,9 @@ int64_t v2vae_ws_offset_gmoments(const v2vae_problem* p);
 
 const char* v2vae_version(void);
 
+/* Text of the last HIP error seen by the calling thread inside this library (debugging aid). */
+const char* v2vae_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,6 +8,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch must be imported first: it brings its own HIP runtime (libamdhip64), and the kernels have to run
+# on that same runtime instance to share torch's device context, streams and allocations.  Loading
+# libv2vae_hip.so first would bind the system runtime instead and the two would not see each other.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libv2vae_hip.so")
 
@@ -40,6 +45,7 @@ class TrainArgs(C.Structure):
 EXPORTS = {
     # name: (restype, argtypes)
     "v2vae_version": (C.c_char_p, []),
+    "v2vae_last_error": (C.c_char_p, []),
     "v2vae_workspace_bytes": (C.c_size_t, [C.POINTER(Problem)]),
     "v2vae_check_problem": (C.c_int, [C.POINTER(Problem)]),
     "v2vae_prep_tables": (C.c_int, [C.POINTER(Problem)] + [C.c_void_p] * 6),
@@ -82,7 +88,8 @@ class V2VAEError(RuntimeError):
 
 def check(rc: int, what: str = ""):
     if rc != OK:
-        raise V2VAEError(f"{what}: {_ERR.get(rc, 'error')} (code {rc})")
+        detail = lib.v2vae_last_error().decode() if rc == ELAUNCH else ""
+        raise V2VAEError(f"{what}: {_ERR.get(rc, 'error')} (code {rc}) {detail}")
 
 
 def pack_sizes(p: Problem):

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <math.h>
+#include <stdio.h>
 
 #include "v2vae_layout.h"
 
@@ -1090,15 +1091,23 @@ __global__ __launch_bounds__(NT) void k_adam(int64_t n, float* __restrict__ p, c
     }
 }
 
-static inline int launch_status() {
-    return hipGetLastError() == hipSuccess ? V2VAE_OK : V2VAE_ELAUNCH;
+static thread_local char g_last_error[256] = "";
+
+static inline int launch_status_at(const char* where) {
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return V2VAE_OK;
+    snprintf(g_last_error, sizeof(g_last_error), "%s: %s", where, hipGetErrorString(e));
+    return V2VAE_ELAUNCH;
 }
+#define launch_status() launch_status_at(__func__)
 
 template <typename K>
 static inline int allow_lds(K kernel, int bytes) {
     if (bytes <= 64 * 1024) return V2VAE_OK;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess
-               ? V2VAE_OK : V2VAE_ELAUNCH;
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) return V2VAE_OK;
+    snprintf(g_last_error, sizeof(g_last_error), "hipFuncSetAttribute(%d bytes of LDS): %s", bytes, hipGetErrorString(e));
+    return V2VAE_ELAUNCH;
 }
 
 }  // namespace v2vae
@@ -1108,6 +1117,8 @@ using namespace v2vae;
 extern "C" {
 
 const char* v2vae_version(void) { return "v2vae-hip 0.1 (gfx950)"; }
+
+const char* v2vae_last_error(void) { return g_last_error; }
 
 int v2vae_check_problem(const v2vae_problem* p) {
     Lay l;

@@ -1,0 +1,88 @@
+"""Halo sharding of one long batch over the GPUs of a node (one process per GPU, RCCL).
+
+The ELBO, the KL term and every gradient are sums over windows / symbols, so one batch splits
+into contiguous symbol blocks.  Rank r owns symbols [own_lo, own_lo + own_cnt): it evaluates their
+KL and per-symbol gradients, the windows n in [own_lo*S, (own_lo+own_cnt)*S) and the equaliser
+gradients of its symbols.  To do that without any exchange of activations it holds
+  * moments for `kmax = (S-1+L-1)//S` extra symbols on each side (recomputed locally), and
+  * received samples for those symbols plus the equaliser's lag halo,
+with zero padding only at the two global ends, i.e. exactly the un-sharded single big batch.
+Per step there are two collectives, both tiny: the scalars [E, KL] (2 doubles) and the flat
+gradient pack.  The reference has no distributed code (its `fit` is a sequential mini-batch loop,
+lib/real_equalization.py:484-502); this module is new.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+
+@dataclass(frozen=True)
+class ShardRanges:
+    own_lo: int
+    own_cnt: int
+    sym_lo: int
+    sym_cnt: int
+    y_lo: int
+    y_len: int
+
+
+def shard_ranges(rank: int, world: int, n_glob: int, sps: int, L: int, l1: int, pad1: int, l2: int) -> ShardRanges:
+    """Contiguous symbol block of `rank` and the symbol / sample halos it needs."""
+    if n_glob % sps:
+        raise ValueError("n_glob must be a multiple of sps")
+    b_glob = n_glob // sps
+    if b_glob < world:
+        raise ValueError("fewer symbols than ranks")
+    base, extra = divmod(b_glob, world)
+    own_lo = rank * base + min(rank, extra)
+    own_cnt = base + (1 if rank < extra else 0)
+    kmax = (sps - 1 + L - 1) // sps
+    pre = (L - 1) // 2
+    p2 = l2 // 2
+    sym_lo = max(0, own_lo - kmax)
+    sym_hi = min(b_glob, own_lo + own_cnt + kmax)
+    left = max(pad1, p2)
+    right = max(l1 - 1 - pad1, p2)
+    y_lo = min(sym_lo * sps - left, (own_lo - kmax) * sps + pre)
+    y_hi = max((sym_hi - 1) * sps + right + 1, (own_lo + own_cnt) * sps + pre)
+    y_lo = max(0, y_lo)
+    y_hi = min(n_glob, y_hi)
+    return ShardRanges(own_lo, own_cnt, sym_lo, sym_hi - sym_lo, y_lo, y_hi - y_lo)
+
+
+class ShardedTrainer:
+    """One data-parallel V2VAE training step over a halo-sharded batch.
+
+    Every rank holds identical parameters and Adam state; after the two all-reduces every rank
+    applies the identical update, so no parameter broadcast is needed after initialisation."""
+
+    def __init__(self, plan, process_group=None):
+        import torch.distributed as dist
+        self.plan = plan
+        self.dist = dist
+        self.group = process_group
+
+    def step(self, *, y, levels, prior, params, grads, adam_m, adam_v, adam_vmax, noise_var, xhat, loss_out, lr, step,
+             learn_scaling=True, adaptive_noise=True, beta1=0.9, beta2=0.999, eps=1e-8):
+        from . import ops
+        plan, dist = self.plan, self.dist
+        n = plan.sizes
+        o = [0, n[0], n[0] + n[1], n[0] + n[1] + n[2], n[0] + n[1] + n[2] + n[3], sum(n)]
+        h1, h2, k1 = params[o[0]:o[1]], params[o[1]:o[2]], params[o[2]:o[3]]
+        k2 = params[o[3]:o[4]] if n[3] else None
+        sc = params[o[4]:o[5]]
+        plan.prep_tables(h1, h2, k1, k2)
+        plan.eq_fwd(y, xhat)
+        plan.demap_moments(xhat, levels, prior, sc, noise_var)
+        plan.elbo_fused(y)
+        plan.reduce_scalars()
+        dist.all_reduce(plan.scal[:2], group=self.group)
+        plan.finalize_scalars()
+        gx = plan.sym_bwd(xhat, levels, prior, sc, noise_var)
+        plan.eq_bwd(y, gx)
+        plan.finish_grads(7, grads[o[0]:o[1]], grads[o[1]:o[2]], grads[o[2]:o[3]],
+                          grads[o[3]:o[4]] if n[3] else None, grads[o[4]:o[5]])
+        dist.all_reduce(grads, group=self.group)
+        nadam = o[4] + (n[4] if learn_scaling else 0)
+        ops.adam_amsgrad_(params, grads, adam_m, adam_v, adam_vmax, lr, step, beta1, beta2, eps, scal=plan.scal,
+                          noise_var=noise_var if adaptive_noise else None, loss_out=loss_out, n=nadam)

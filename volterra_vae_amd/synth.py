@@ -60,3 +60,53 @@ def nonlinear_isi(n_symbols: int, constellation: np.ndarray, sps: int, snr_db: f
     else:
         noise = rng.standard_normal(out.shape) * noise_std
     return out + noise, syms
+
+
+_NORM_CACHE = {}
+
+
+def _wh_chain(x, sps, fir1, fir2, poly):
+    x = np.convolve(x, _lowpass_pulse(sps), mode="same")
+    z = np.convolve(x, np.asarray(fir1), mode="same")
+    w = poly[0] * z + poly[1] * z * z
+    return np.convolve(w, np.asarray(fir2), mode="same")
+
+
+def nonlinear_isi_range(seed: int, constellation: np.ndarray, sps: int, snr_db: float, sym_lo: int, sym_hi: int,
+                        b_glob: int, fir1=FIR1, fir2=FIR2, poly=POLY, block: int = 1 << 16, margin: int = 32):
+    """Samples [sym_lo*sps, sym_hi*sps) of one global b_glob-symbol sequence, reproducible from
+    (seed, symbol index) alone, so that ranks holding overlapping ranges see identical samples.
+    Symbols and noise are drawn per `block` symbols from generators seeded by (seed, kind, block id);
+    the normalisation constants come from block 0 so that they do not depend on the range."""
+    constellation = np.asarray(constellation)
+    cplx = np.iscomplexobj(constellation)
+
+    def block_syms(j):
+        rng = np.random.default_rng([seed, 0, j])
+        return constellation[rng.integers(0, len(constellation), size=block)]
+
+    def block_noise(j):
+        rng = np.random.default_rng([seed, 1, j])
+        if cplx:
+            return (rng.standard_normal(block * sps) + 1j * rng.standard_normal(block * sps)) / np.sqrt(2.0)
+        return rng.standard_normal(block * sps)
+
+    key = (seed, sps, tuple(fir1), tuple(fir2), tuple(poly), constellation.tobytes(), block)
+    if key not in _NORM_CACHE:
+        x0 = np.zeros(block * sps, dtype=constellation.dtype)
+        x0[::sps] = block_syms(0)
+        o0 = _wh_chain(x0, sps, fir1, fir2, poly)
+        _NORM_CACHE[key] = (np.mean(o0), np.std(o0))
+    mean, std = _NORM_CACHE[key]
+
+    lo = max(0, sym_lo - margin)
+    hi = min(b_glob, sym_hi + margin)
+    j0, j1 = lo // block, (hi - 1) // block
+    syms = np.concatenate([block_syms(j) for j in range(j0, j1 + 1)])[lo - j0 * block: hi - j0 * block]
+    x = np.zeros((hi - lo) * sps, dtype=constellation.dtype)
+    x[::sps] = syms
+    out = (_wh_chain(x, sps, fir1, fir2, poly) - mean) / std
+    out = out[(sym_lo - lo) * sps: (sym_hi - lo) * sps]
+    n0, n1 = sym_lo // block, (sym_hi - 1) // block
+    noise = np.concatenate([block_noise(j) for j in range(n0, n1 + 1)])[(sym_lo - n0 * block) * sps: (sym_hi - n0 * block) * sps]
+    return out + noise * np.sqrt(10.0 ** (-snr_db / 10.0)), syms[sym_lo - lo: sym_hi - lo]
