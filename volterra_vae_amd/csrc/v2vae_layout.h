@@ -17,7 +17,7 @@ namespace v2vae {
 constexpr int NT = 256;         // threads per workgroup (4 waves of 64)
 constexpr int MAX_C = 16;       // amplitude levels per stream
 constexpr int EQ_TB = 256;      // symbols per equaliser tile
-constexpr int LDS_BUDGET = 150 * 1024;
+constexpr int LDS_BUDGET = 163000;  // one workgroup may use (almost) all 160 KiB of a CU
 constexpr int SCRATCH_F = 4096; // floats of LDS scratch for cross-chunk reductions
 constexpr int MAX_BLOCKS = 512; // persistent workgroups per kernel (2 per CU)
 

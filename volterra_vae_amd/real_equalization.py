@@ -1,0 +1,418 @@
+"""Drop-in blind V2VAE equalisers for real PAM, interface of lib/real_equalization.py.
+
+Class names, constructor signatures, attributes, method names, printed messages and error
+conventions follow the reference (`GenericTorchBlindEqualizer` :434-542,
+`GenericTorchBlindProbabilisticEqualizer` :545-560, `VAESecondVolterraForward` :739-958,
+`LinearV2VAE` :961-985, `SecondVolterraV2VAE` :988-1011, `SecondVolterraV2VAENoNoiseScaling`
+:1014-1037).  The arithmetic runs in the HIP kernels of libv2vae_hip.so:
+
+* `fit` drives one fused kernel sequence per mini-batch (forward, ELBO, backward, Adam-AMSGrad)
+  with no host synchronisation except where the reference prints the loss;
+* `forward`, `_calculate_loss` and `_update_model` remain separately callable and autograd
+  compatible, so user code that steps the model by hand keeps working.
+
+All trainable tensors are views into one flat float32 buffer [h1 | h2 | equaliser | noise scaling],
+which is what lets the optimiser be a single kernel launch.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops
+from .ops import ElboLossFn, Plan
+from .torch_components import SecondOrderVolterraSeries, StridedFIREqualiser, _check_dtype, _resolve_device
+
+
+class PackedAdamAMSGrad(torch.optim.Optimizer):
+    """torch.optim.Adam(amsgrad=True) semantics (what lib/real_equalization.py:457-459 constructs) on
+    parameters that are views of one flat buffer; state lives in flat buffers of the same layout."""
+
+    def __init__(self, param_groups, pack, offsets, lr, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(param_groups, dict(lr=lr, betas=betas, eps=eps, amsgrad=True))
+        self.pack = pack
+        self.offsets = offsets  # {id(param): (start, numel)}
+        self.exp_avg = torch.zeros_like(pack)
+        self.exp_avg_sq = torch.zeros_like(pack)
+        self.max_exp_avg_sq = torch.zeros_like(pack)
+        self.flat_grad = torch.zeros_like(pack)
+        self.step_count = 0
+        self.n_trainable = max(s + n for s, n in offsets.values())
+
+    def current_lr(self):
+        return float(self.param_groups[0]["lr"])
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        self.step_count += 1
+        segs = []
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                s, n = self.offsets[id(p)]
+                self.flat_grad[s:s + n].copy_(p.grad.reshape(-1))
+                segs.append((s, n, float(group["lr"]), group["betas"], group["eps"]))
+        segs.sort()
+        merged = []
+        for seg in segs:  # merge adjacent sections with identical hyper-parameters into one launch
+            if merged and merged[-1][0] + merged[-1][1] == seg[0] and merged[-1][2:] == seg[2:]:
+                merged[-1] = (merged[-1][0], merged[-1][1] + seg[1]) + merged[-1][2:]
+            else:
+                merged.append(seg)
+        for s, n, lr, betas, eps in merged:
+            ops.adam_amsgrad_(self.pack[s:], self.flat_grad[s:], self.exp_avg[s:], self.exp_avg_sq[s:],
+                              self.max_exp_avg_sq[s:], lr, self.step_count, betas[0], betas[1], eps, n=n)
+
+
+class GenericTorchBlindEqualizer(object):
+    """Parent class for blind equalisers with torch-style optimisation (lib/real_equalization.py:434-542)."""
+    IS_PROBABILISTIC = False
+
+    def __init__(self, samples_per_symbol, batch_size, learning_rate, dtype=torch.float32, torch_device=None,
+                 lr_schedule='step') -> None:
+        _check_dtype(dtype)
+        self.samples_per_symbol = samples_per_symbol
+        self.batch_size = batch_size
+        self.torch_device = _resolve_device(torch_device)
+        self.dtype = dtype
+        self.loss_print_interval = 100
+        self.learning_rate = learning_rate
+        self.optimizer = None
+        self.lr_schedule = lr_schedule
+
+    def _check_input(self, input_array):
+        n_batches = len(input_array) // self.samples_per_symbol // self.batch_size
+        if n_batches * self.samples_per_symbol * self.batch_size != len(input_array):
+            print(f"Warning! Number of samples in receiver signal does not match with a multiplum of the symbol length ({self.samples_per_symbol})")
+        return n_batches
+
+    def initialize_optimizer(self):
+        raise NotImplementedError
+
+    def _make_lr_schedule(self, n_batches):
+        # StepLR: 10 steps down to 1 % of the initial rate over one fit() call (:476-480)
+        steps = 10
+        reduction = 0.01
+        gamma = np.exp(np.log(reduction) / steps)
+        return torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=n_batches // steps, gamma=gamma)
+
+    def fit(self, y_input):
+        raise NotImplementedError
+
+    def apply(self, y_input):
+        y = torch.from_numpy(np.ascontiguousarray(y_input)).type(self.dtype).to(device=self.torch_device)
+        with torch.set_grad_enabled(False):
+            y_eq = self.forward(y)
+        return y_eq.cpu().numpy()
+
+    def get_parameters(self):
+        raise NotImplementedError
+
+    def _update_model(self, loss):
+        raise NotImplementedError
+
+    def forward(self, y):
+        raise NotImplementedError
+
+    def _calculate_loss(self, xhat, y):
+        raise NotImplementedError
+
+    def print_model_parameters(self):
+        raise NotImplementedError
+
+    def train_mode(self):
+        raise NotImplementedError
+
+    def eval_mode(self):
+        raise NotImplementedError
+
+    def __repr__(self) -> str:
+        raise NotImplementedError
+
+
+class GenericTorchBlindProbabilisticEqualizer(GenericTorchBlindEqualizer):
+    """Adds probabilistic outputs (lib/real_equalization.py:545-560)."""
+    IS_PROBABILISTIC = True
+
+    def estimate_symbol_probs(self, y_input):
+        y = torch.from_numpy(np.ascontiguousarray(y_input)).type(self.dtype).to(device=self.torch_device)
+        with torch.set_grad_enabled(False):
+            q_eq = self.forward_probs(y)
+        return q_eq.cpu().numpy()
+
+    def forward_probs(self, y_in):
+        raise NotImplementedError
+
+
+class VAESecondVolterraForward(GenericTorchBlindProbabilisticEqualizer):
+    """Blind VAE equaliser with a second-order Volterra channel model (lib/real_equalization.py:739-958)."""
+
+    def __init__(self, channel_memory, learning_rate, constellation: np.ndarray,
+                 samples_per_symbol, batch_size, dtype=torch.float32, noise_variance=1.0,
+                 adaptive_noise_variance=True, noise_scaling=True,
+                 torch_device=None, lr_schedule='step', **equaliser_kwargs) -> None:
+        super().__init__(samples_per_symbol, batch_size, learning_rate, dtype, torch_device, lr_schedule)
+        assert (samples_per_symbol <= channel_memory)
+        self.channel_memory = L = channel_memory
+        self.constellation = torch.from_numpy(np.asarray(constellation)).type(self.dtype).to(self.torch_device).contiguous()
+        self.constellation_size = C = len(self.constellation)
+        self._eq_sizes = self._equaliser_sizes(**equaliser_kwargs)  # (l1, l2)
+        l1, l2 = self._eq_sizes
+        n = [L, L * L, l1, l2 * l2, C]
+        o = np.cumsum([0] + n)
+        self._pack = torch.zeros(int(o[-1]), dtype=self.dtype, device=self.torch_device)
+        self._sections = [(int(o[i]), n[i]) for i in range(5)]
+
+        # channel model (:753-761): Dirac first-order kernel, zero second-order kernel
+        self.channel_h1 = self._pack[o[0]:o[1]]
+        self.channel_h1.data[L // 2] = 1.0
+        self.channel_h1.requires_grad = True
+        self.channel_h2 = self._pack[o[1]:o[2]].view(L, L)
+        self.channel_h2.requires_grad = True
+
+        # equaliser (:764)
+        self._eq_storage = (self._pack[o[2]:o[3]], self._pack[o[3]:o[4]].view(l2, l2) if l2 else None)
+        self.equaliser = self.initialize_equaliser(**equaliser_kwargs)
+        self.equaliser._host = (L, C)
+
+        # noise variance (:767-769): a device scalar that the kernels read and (if adaptive) update in place
+        self._noise_var = torch.full((1,), float(noise_variance), dtype=self.dtype, device=self.torch_device)
+        self.adaptive_noise_variance = adaptive_noise_variance
+        self.learning_rate_second_order = learning_rate
+
+        # per-symbol noise scaling (:779-781)
+        self.noise_scaling = self._pack[o[4]:o[5]]
+        self.noise_scaling.data.fill_(1.0)
+        self.learnable_noise_scaling = noise_scaling
+        self.noise_scaling.requires_grad = True if self.learnable_noise_scaling else False
+
+        self.constellation_prior = torch.ones((C,), dtype=self.dtype, device=self.torch_device) / C
+        self.sm = torch.nn.Softmax(dim=-1)
+        self.epsilon = 1e-12
+        self._plans = {}
+
+    # ---- attribute with the reference's name and tensor type
+    @property
+    def noise_variance(self):
+        return self._noise_var[0]
+
+    @noise_variance.setter
+    def noise_variance(self, value):
+        with torch.no_grad():
+            self._noise_var[0] = float(value) if not torch.is_tensor(value) else value.detach().to(self._noise_var)
+
+    # ---- plumbing
+    def _equaliser_sizes(self, **equaliser_kwargs):
+        raise NotImplementedError
+
+    def _pad1(self):
+        l1, l2 = self._eq_sizes
+        return l1 // 2 if l2 else (l1 - 1) // 2
+
+    def _plan(self, n_samples) -> Plan:
+        if n_samples not in self._plans:
+            l1, l2 = self._eq_sizes
+            self._plans[n_samples] = Plan(ns=1, sps=self.samples_per_symbol, l1=l1, pad1=self._pad1(), l2=l2,
+                                          L=self.channel_memory, C_levels=self.constellation_size, n_glob=n_samples,
+                                          device=self.torch_device)
+        return self._plans[n_samples]
+
+    def _levels2d(self):
+        return self.constellation.view(1, -1)
+
+    def initialize_optimizer(self):
+        groups = self.get_parameters()
+        offsets = {}
+        for g in groups:
+            g["params"] = list(g["params"]) if not torch.is_tensor(g["params"]) else [g["params"]]
+        named = {"channel_h1": 0, "channel_h2": 1, "noise_scale": 4}
+        for g in groups:
+            if g["name"] == "equaliser":
+                s = self._sections[2][0]
+                for p in g["params"]:
+                    offsets[id(p)] = (s, p.numel())
+                    s += p.numel()
+            else:
+                sec = self._sections[named[g["name"]]]
+                offsets[id(g["params"][0])] = sec
+        self.optimizer = PackedAdamAMSGrad(groups, self._pack, offsets, lr=self.learning_rate)
+
+    def get_parameters(self):
+        params = [{'params': self.channel_h1, 'name': 'channel_h1'},
+                  {'params': self.channel_h2, "lr": self.learning_rate_second_order, 'name': 'channel_h2'},
+                  {'params': self.equaliser.parameters(), 'name': 'equaliser'}]
+        if self.learnable_noise_scaling:
+            params += [{'params': self.noise_scaling, 'name': 'noise_scale'}]
+        return params
+
+    def initialize_equaliser(self, **equaliser_kwargs) -> torch.nn.Module:
+        raise NotImplementedError
+
+    def forward(self, y) -> torch.Tensor:
+        raise NotImplementedError
+
+    def forward_probs(self, y_in):
+        y = self.forward(y_in)
+        return self._soft_demapping(y)
+
+    def _soft_demapping(self, xhat):
+        """[C, B] posteriors (:816-823) through v2vae_demap_moments."""
+        xh = xhat.detach().to(self.dtype).reshape(1, -1).contiguous()
+        B = xh.shape[1]
+        plan = self._plan(B * self.samples_per_symbol)
+        q = torch.empty((1, self.constellation_size, B), dtype=self.dtype, device=self.torch_device)
+        plan.demap_moments(xh, self._levels2d(), self.constellation_prior.view(1, -1), self.noise_scaling.detach().view(1, -1),
+                           self._noise_var, q_out=q)
+        return q[0]
+
+    def _calculate_loss(self, xhat, y):
+        """ELBO (:836-925) incl. the noise-variance side effect (:921-923); 0-d tensor with grad_fn."""
+        n = y.shape[-1]
+        plan = self._plan(n)
+        loss, E = ElboLossFn.apply(plan, xhat.reshape(1, -1), y.reshape(1, -1).to(self.dtype).contiguous(), self.channel_h1,
+                                   self.channel_h2, self.noise_scaling.view(1, -1), self._noise_var,
+                                   self._levels2d(), self.constellation_prior.view(1, -1).contiguous())
+        if self.adaptive_noise_variance:
+            with torch.no_grad():
+                self._noise_var[0] = E / (n - self.channel_memory + 1)
+        return loss
+
+    def _update_model(self, loss):
+        loss.backward(retain_graph=True)
+        self.optimizer.step()
+        self.channel_h1.grad = None
+        self.channel_h2.grad = None
+        self.equaliser.zero_grad()
+        if self.learnable_noise_scaling:
+            self.noise_scaling.grad = None
+
+    def fit(self, y_input):
+        """Mini-batch training loop of lib/real_equalization.py:461-504, one fused kernel sequence per batch."""
+        n_batches = self._check_input(y_input)
+        if self.optimizer is None:
+            raise Exception("Optimizer has not been initialized yet. Please call 'initialize_optimizer' before proceeding to 'fit'.")
+        y = torch.from_numpy(np.ascontiguousarray(y_input)).type(self.dtype).to(device=self.torch_device)
+        S, B = self.samples_per_symbol, self.batch_size
+        y_eq = torch.zeros((y.shape[-1] // S,), dtype=y.dtype, device=self.torch_device)
+        lr_schedule = self._make_lr_schedule(n_batches) if self.lr_schedule else None
+        losses = torch.zeros(max(n_batches, 1), dtype=torch.float32, device=self.torch_device)
+        opt = self.optimizer
+        opt._opt_called = True  # the fused step below is the optimizer step
+        plan = self._plan(B * S) if n_batches else None
+        levels, prior = self._levels2d(), self.constellation_prior.view(1, -1).contiguous()
+        for n in range(n_batches):
+            ysl = y[n * B * S:(n + 1) * B * S].view(1, -1)
+            lr_now = opt.current_lr()
+            opt.step_count += 1
+            plan.train_step(y=ysl, levels=levels, prior=prior, params=self._pack, grads=opt.flat_grad, adam_m=opt.exp_avg,
+                            adam_v=opt.exp_avg_sq, adam_vmax=opt.max_exp_avg_sq, noise_var=self._noise_var,
+                            xhat=y_eq[n * B:(n + 1) * B], loss_out=losses[n:n + 1], lr=lr_now, step=opt.step_count,
+                            learn_scaling=self.learnable_noise_scaling, adaptive_noise=self.adaptive_noise_variance)
+            if n % self.loss_print_interval == 0:
+                lrprint = lr_schedule.get_last_lr()[-1] if self.lr_schedule else self.learning_rate
+                print(f"Batch {n}, Loss: {losses[n].item():.3f} (LR: {lrprint:.3e})")
+            if lr_schedule:
+                lr_schedule.step()
+        loss_curve = losses[:n_batches].cpu().numpy().astype(np.float64)
+        return y_eq.cpu().numpy(), loss_curve
+
+    def print_model_parameters(self):
+        print(f"Equaliser: {self.equaliser}")
+        print(f"Channel (1st order): {self.channel_h1}")
+        print(f"Channel (2nd order): {self.channel_h2}")
+        print(f"Noise variance: {self.noise_variance}")
+        if self.learnable_noise_scaling:
+            print(f"Noise scaling: {self.noise_scaling}")
+
+    def train_mode(self):
+        self.channel_h1.requires_grad = True
+        self.channel_h2.requires_grad = True
+        self.equaliser.train()
+
+    def eval_mode(self):
+        self.channel_h1.requires_grad = False
+        self.channel_h2.requires_grad = False
+        self.equaliser.eval()
+
+
+class LinearV2VAE(VAESecondVolterraForward):
+    """V2VAE with a linear (strided FIR) equaliser, lib/real_equalization.py:961-985."""
+
+    def __init__(self, channel_memory, learning_rate, constellation: np.ndarray, samples_per_symbol,
+                 batch_size, dtype=torch.float32, noise_variance=1, adaptive_noise_variance=True,
+                 torch_device=None, lr_schedule='step', **equaliser_kwargs) -> None:
+        super().__init__(channel_memory=channel_memory, learning_rate=learning_rate, constellation=constellation,
+                         samples_per_symbol=samples_per_symbol, batch_size=batch_size, dtype=dtype,
+                         noise_variance=noise_variance, adaptive_noise_variance=adaptive_noise_variance,
+                         noise_scaling=True, torch_device=torch_device, lr_schedule=lr_schedule,
+                         **equaliser_kwargs)
+
+    def _equaliser_sizes(self, **equaliser_kwargs):
+        return equaliser_kwargs['equaliser_n_taps'], 0
+
+    def initialize_equaliser(self, **equaliser_kwargs):
+        return StridedFIREqualiser(equaliser_kwargs['equaliser_n_taps'], self.samples_per_symbol, dtype=self.dtype,
+                                   torch_device=self.torch_device, _storage=self._eq_storage[0])
+
+    def forward(self, y):
+        return self.equaliser.forward(y[None, None, :]).squeeze()
+
+    def __repr__(self) -> str:
+        return "LinV2VAE"
+
+
+class SecondVolterraV2VAE(VAESecondVolterraForward):
+    """V2VAE with a second-order Volterra equaliser, lib/real_equalization.py:988-1011."""
+
+    def __init__(self, channel_memory, learning_rate, constellation: np.ndarray, samples_per_symbol,
+                 batch_size, dtype=torch.float32, noise_variance=1, adaptive_noise_variance=True,
+                 torch_device=None, lr_schedule='step', **equaliser_kwargs) -> None:
+        super().__init__(channel_memory=channel_memory, learning_rate=learning_rate, constellation=constellation,
+                         samples_per_symbol=samples_per_symbol, batch_size=batch_size, dtype=dtype,
+                         noise_variance=noise_variance, adaptive_noise_variance=adaptive_noise_variance,
+                         noise_scaling=True, torch_device=torch_device, lr_schedule=lr_schedule,
+                         **equaliser_kwargs)
+
+    def _equaliser_sizes(self, **equaliser_kwargs):
+        return equaliser_kwargs['equaliser_n_lags1'], equaliser_kwargs['equaliser_n_lags2']
+
+    def initialize_equaliser(self, **equaliser_kwargs):
+        return SecondOrderVolterraSeries(n_lags1=equaliser_kwargs['equaliser_n_lags1'],
+                                         n_lags2=equaliser_kwargs['equaliser_n_lags2'],
+                                         samples_per_symbol=self.samples_per_symbol,
+                                         dtype=self.dtype, torch_device=self.torch_device, _storage=self._eq_storage)
+
+    def forward(self, y):
+        return self.equaliser.forward(y)
+
+    def __repr__(self) -> str:
+        return "SecondVolterraV2VAE"
+
+
+class SecondVolterraV2VAENoNoiseScaling(VAESecondVolterraForward):
+    """Same with the per-symbol noise scaling frozen at 1, lib/real_equalization.py:1014-1037."""
+
+    def __init__(self, channel_memory, learning_rate, constellation: np.ndarray, samples_per_symbol,
+                 batch_size, dtype=torch.float32, noise_variance=1, adaptive_noise_variance=True,
+                 torch_device=None, lr_schedule='step', **equaliser_kwargs) -> None:
+        super().__init__(channel_memory=channel_memory, learning_rate=learning_rate, constellation=constellation,
+                         samples_per_symbol=samples_per_symbol, batch_size=batch_size, dtype=dtype,
+                         noise_variance=noise_variance, adaptive_noise_variance=adaptive_noise_variance,
+                         noise_scaling=False, torch_device=torch_device, lr_schedule=lr_schedule,
+                         **equaliser_kwargs)
+
+    def _equaliser_sizes(self, **equaliser_kwargs):
+        return equaliser_kwargs['equaliser_n_lags1'], equaliser_kwargs['equaliser_n_lags2']
+
+    def initialize_equaliser(self, **equaliser_kwargs):
+        return SecondOrderVolterraSeries(n_lags1=equaliser_kwargs['equaliser_n_lags1'],
+                                         n_lags2=equaliser_kwargs['equaliser_n_lags2'],
+                                         samples_per_symbol=self.samples_per_symbol,
+                                         dtype=self.dtype, torch_device=self.torch_device, _storage=self._eq_storage)
+
+    def forward(self, y):
+        return self.equaliser.forward(y)
+
+    def __repr__(self) -> str:
+        return "SecondVolterraV2VAE(Beta=1.0)"
