@@ -10,6 +10,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "v2vae_layout.h"
 
@@ -116,6 +117,20 @@ int make_layout(const v2vae_problem* p, Lay* out) {
         int64_t nb = (l.sym_cnt + NT - 1) / NT;
         l.nblk_sym = (int)(nb < 1024 ? nb : 1024);
     }
+    // ---- matrix-core ELBO path: complex model, <= 16 active taps per stream and phase, S in {1, 2}
+    l.use_cx = (l.mode == 1 && l.LE <= 16 && l.S <= 2 && getenv("V2VAE_FORCE_GENERIC") == nullptr) ? 1 : 0;
+    {
+        const int ts = CX_TWB - l.kmax;
+        l.ntile_cx = (int)((l.own_cnt + ts - 1) / ts);
+        l.nblk_cx = l.ntile_cx < CX_BLOCKS ? l.ntile_cx : CX_BLOCKS;
+        l.lds_cx = (8 * CX_MS + CX_MS + 2 * l.S * CX_TWB + l.S * 6 * 16 * CX_TWB + 4 * 32 * CX_TP) * 4;
+        l.nblk_E = l.use_cx ? l.nblk_cx : l.nblk_elbo;
+    }
+    // ---- matrix-core equaliser path: complex, second-order lags odd <= 31, centred first-order window inside it
+    l.use_eqcx = (l.mode == 1 && l.l2 >= 1 && l.l2 <= 31 && (l.l1 & 1) && l.l1 <= l.l2 && l.pad1 == l.l1 / 2 &&
+                  getenv("V2VAE_FORCE_GENERIC") == nullptr) ? 1 : 0;
+    l.eqcx_lk = (l.l2 + 2) & ~1;           // lags per stream, even and > l2 (the spare lag carries a zero coefficient)
+    l.eqcx_steps = l.eqcx_lk;              // 2 streams * lk lags / 2 per MFMA step
     l.rec_elbo = l.S * rec_elbo_phase(l);
     l.rec_eq = l.ns * l.LT2p * l.LT2p + l.nk1;
     l.rec_sym = l.ns * l.C;
@@ -137,7 +152,14 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     l.o_tot_elbo = take(l.rec_elbo);
     l.o_tot_eq = take(l.rec_eq);
     l.o_tot_sym = take(l.rec_sym);
-    l.o_Epart = take(2 * (int64_t)l.nblk_elbo);
+    l.o_cxH = take((int64_t)l.S * 2 * 256);
+    l.o_cxh1 = take((int64_t)l.S * 2 * 16);
+    l.o_part_cx = take(l.use_cx ? (int64_t)l.nblk_cx * 4 * CX_REC : 0);
+    l.o_tot_cx = take((int64_t)l.S * CX_REC);
+    l.o_eqcxA = take(l.use_eqcx ? (int64_t)2 * l.eqcx_steps * 64 : 0);
+    l.o_part_eqcx = take(l.use_eqcx ? (int64_t)l.nblk_eq * 4 * 4096 : 0);
+    l.o_tot_eqcx = take(l.use_eqcx ? 4096 : 0);
+    l.o_Epart = take(2 * (int64_t)(l.nblk_elbo > l.nblk_cx ? l.nblk_elbo : l.nblk_cx));
     l.o_KLpart = take(2 * (int64_t)l.nblk_sym);
     l.total_floats = o;
     *out = l;
@@ -226,6 +248,20 @@ __global__ __launch_bounds__(NT) void k_prep_tables(Lay l, const float* __restri
         ws[l.o_h1c + idx] = hv;
         ws[l.o_dc + idx] = dv;
         ws[l.o_dqc + idx] = dqv;
+    }
+    if (l.use_cx && h1) {
+        for (int idx = tid; idx < l.S * 2 * 256; idx += nth) {
+            const int rp = idx / 256, rem = idx - rp * 256;
+            const int r = rp / 2, pl = rp - r * 2;
+            const int a = tap_index(l, r, rem / 16), b = tap_index(l, r, rem % 16);  // compact taps of stream 0
+            ws[l.o_cxH + idx] = (rem / 16 < l.LE && rem % 16 < l.LE && a >= 0 && b >= 0) ? stacked_quad(l.mode, h2, l.L, pl, a, b) : 0.f;
+        }
+        for (int idx = tid; idx < l.S * 2 * 16; idx += nth) {
+            const int rp = idx / 16, x = idx - rp * 16;
+            const int r = rp / 2, pl = rp - r * 2;
+            const int a = tap_index(l, r, x);
+            ws[l.o_cxh1 + idx] = (x < l.LE && a >= 0) ? stacked_lin(l.mode, h1, l.L, pl, a) : 0.f;
+        }
     }
     const int nm = l.S * l.ns * l.LTp * l.LTp;
     for (int idx = tid; h1 && idx < nm; idx += nth) {
@@ -936,7 +972,7 @@ __global__ __launch_bounds__(NT) void k_reduce_scalars(Lay l, const float* __res
     const double* Ep = reinterpret_cast<const double*>(ws + l.o_Epart);
     const double* Kp = reinterpret_cast<const double*>(ws + l.o_KLpart);
     double e = 0.0, k = 0.0;
-    for (int i = threadIdx.x; i < l.nblk_elbo; i += NT) e += Ep[i];
+    for (int i = threadIdx.x; i < l.nblk_E; i += NT) e += Ep[i];
     for (int i = threadIdx.x; i < l.nblk_sym; i += NT) k += Kp[i];
     const double es = block_sum_double(e, red);
     const double ks = block_sum_double(k, red);
@@ -1149,6 +1185,7 @@ int v2vae_prep_tables(const v2vae_problem* p, const float* h1, const float* h2, 
     // either group may be absent (NULL): channel tables need h1 and h2, equaliser tables k1 (and k2 if l2 > 0)
     if (!ws || (!h1 && !k1) || (h1 && !h2) || (k1 && l.l2 > 0 && !k2)) return V2VAE_EINVAL;
     hipLaunchKernelGGL(k_prep_tables, dim3(16), dim3(NT), 0, (hipStream_t)stream, l, h1, h2, k1, k2, (float*)ws);
+    if (k1 && l.use_eqcx) launch_prep_eqcx(l, k1, k2, (float*)ws, (hipStream_t)stream);
     return launch_status();
 }
 
@@ -1157,6 +1194,10 @@ int v2vae_eq_fwd(const v2vae_problem* p, const float* y, const void* ws, float* 
     int rc = make_layout(p, &l);
     if (rc) return rc;
     if (!y || !ws || !xhat) return V2VAE_EINVAL;
+    if (l.use_eqcx) {
+        launch_eq_fwd_cx(l, y, (const float*)ws, xhat, (hipStream_t)stream);
+        return launch_status();
+    }
     rc = allow_lds(k_eq_fwd, l.lds_eq);
     if (rc) return rc;
     const int nblk = (int)((l.sym_cnt + EQ_TB - 1) / EQ_TB);
@@ -1191,6 +1232,10 @@ int v2vae_elbo_fused(const v2vae_problem* p, const float* y, void* ws, void* str
     if (rc) return rc;
     if (!y || !ws) return V2VAE_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    if (l.use_cx) {
+        rc = launch_elbo_cx(l, y, (float*)ws, st);
+        return rc ? rc : launch_status();
+    }
 #define V2VAE_LAUNCH_ELBO(M)                                                                              \
     do {                                                                                                  \
         rc = allow_lds(k_elbo<M>, l.lds_elbo);                                                            \
@@ -1240,6 +1285,10 @@ int v2vae_eq_bwd(const v2vae_problem* p, const float* y, const float* gxhat, voi
     if (rc) return rc;
     if (!y || !gxhat || !ws) return V2VAE_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    if (l.use_eqcx) {
+        launch_eq_bwd_cx(l, y, gxhat, (float*)ws, st);
+        return launch_status();
+    }
 #define V2VAE_LAUNCH_EQB(M)                                                                                   \
     do {                                                                                                      \
         rc = allow_lds(k_eq_bwd<M>, l.lds_eq);                                                                \
@@ -1262,7 +1311,9 @@ int v2vae_finish_grads(const v2vae_problem* p, void* ws, const double* scal, con
     if (!ws || !scal) return V2VAE_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     float* w = (float*)ws;
-    if (which & 1) {
+    if ((which & 1) && l.use_cx) {
+        launch_finish_channel_cx(l, w, scal, grad_scale, g_h1, g_h2, st);
+    } else if (which & 1) {
         hipLaunchKernelGGL(k_sum_records, dim3((l.rec_elbo + NT - 1) / NT), dim3(NT), 0, st, w + l.o_part_elbo, l.rec_elbo,
                            l.nblk_elbo, w + l.o_tot_elbo);
         const int n = l.ns * l.L + l.ns * l.L * l.L;
@@ -1274,7 +1325,9 @@ int v2vae_finish_grads(const v2vae_problem* p, void* ws, const double* scal, con
         if (g_scaling)
             hipLaunchKernelGGL(k_copy, dim3((l.rec_sym + NT - 1) / NT), dim3(NT), 0, st, (const float*)(w + l.o_tot_sym), g_scaling, l.rec_sym);
     }
-    if (which & 4) {
+    if ((which & 4) && l.use_eqcx) {
+        launch_finish_equaliser_cx(l, w, g_k1, g_k2, st);
+    } else if (which & 4) {
         hipLaunchKernelGGL(k_sum_records, dim3((l.rec_eq + NT - 1) / NT), dim3(NT), 0, st, w + l.o_part_eq, l.rec_eq,
                            l.nblk_eq, w + l.o_tot_eq);
         const int n = l.ns * l.l1 + l.ns * l.l2 * l.l2;

@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <hip/hip_runtime.h>
+
 #include "../../include/v2vae_hip.h"
 
 #if defined(__HIPCC__)
@@ -20,6 +22,12 @@ constexpr int EQ_TB = 256;      // symbols per equaliser tile
 constexpr int LDS_BUDGET = 163000;  // one workgroup may use (almost) all 160 KiB of a CU
 constexpr int SCRATCH_F = 4096; // floats of LDS scratch for cross-chunk reductions
 constexpr int MAX_BLOCKS = 512; // persistent workgroups per kernel (2 per CU)
+// matrix-core ELBO kernel for the complex model (v2vae_elbo_cx.hip)
+constexpr int CX_TWB = 128;          // windows per phase per block tile
+constexpr int CX_MS = CX_TWB + 48;   // staged symbol slots per block tile
+constexpr int CX_TP = 33;            // row pitch of the per-wave transposing buffer
+constexpr int CX_REC = 2112;         // floats per wave record: R 32x32, Ps 32x32, 4 vectors of 16
+constexpr int CX_BLOCKS = 256;       // one workgroup per CU (the LDS image takes most of a CU)
 
 struct Lay {
     int ns, mode, S, l1, pad1, l2, L, C;
@@ -36,6 +44,12 @@ struct Lay {
     int ntile_eq, nblk_eq, nitems_eq, nchunk_eq, maxi_eq, nk1;
     int lds_eq;              // bytes (forward and backward use the same carve)
     int nblk_sym;
+    // matrix-core ELBO path
+    int use_cx, ntile_cx, nblk_cx, lds_cx, nblk_E;
+    int64_t o_cxH, o_cxh1, o_part_cx, o_tot_cx;
+    // matrix-core equaliser path
+    int use_eqcx, eqcx_lk, eqcx_steps;
+    int64_t o_eqcxA, o_part_eqcx, o_tot_eqcx;
     // record sizes of the per-workgroup partial sums (floats)
     int rec_elbo, rec_eq, rec_sym;
     // workspace offsets in floats
@@ -49,5 +63,16 @@ struct Lay {
 V2VAE_HD inline int rec_elbo_phase(const Lay& l) { return l.ns * l.LTp * l.LTp + l.LTp * l.LTp + l.ns * 3 * l.LTp; }
 
 int make_layout(const v2vae_problem* p, Lay* out);
+
+// v2vae_elbo_cx.hip
+int launch_elbo_cx(const Lay& l, const float* y, float* ws, hipStream_t st);
+void launch_finish_channel_cx(const Lay& l, float* ws, const double* scal, const float* grad_scale, float* g_h1, float* g_h2,
+                              hipStream_t st);
+
+// v2vae_eq_cx.hip
+int launch_prep_eqcx(const Lay& l, const float* k1, const float* k2, float* ws, hipStream_t st);
+int launch_eq_fwd_cx(const Lay& l, const float* y, const float* ws, float* xhat, hipStream_t st);
+int launch_eq_bwd_cx(const Lay& l, const float* y, const float* gx, float* ws, hipStream_t st);
+void launch_finish_equaliser_cx(const Lay& l, float* ws, float* g_k1, float* g_k2, hipStream_t st);
 
 }  // namespace v2vae
