@@ -265,14 +265,11 @@ __global__ __launch_bounds__(NT) void k_elbo_cx(Lay l, const float* __restrict__
         }
     }
 
-    // ---- per-wave partial record: R [32][32], Ps [32][32], vectors [4][16]
-    float* rec = ws + l.o_part_cx + ((size_t)blockIdx.x * 4 + wv) * CX_REC;
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-        const int row = (g & 3) + 8 * (g >> 2) + 4 * h;
-        rec[row * 32 + i] = R[g];
-        rec[1024 + row * 32 + i] = Ps[g];
-    }
+    // ---- one record per (block, phase): R [32][32], Ps [32][32], vectors [4][16]; the waves of a phase are
+    //      reduced through LDS in a fixed order
+    __syncthreads();
+    float* img = s_D + (size_t)r * CX_REC;
+    float vsum[8][4];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         float v0 = ghr[q], v1 = ghi[q], v2 = gdr[q], v3 = gdi[q];
@@ -281,12 +278,32 @@ __global__ __launch_bounds__(NT) void k_elbo_cx(Lay l, const float* __restrict__
             v0 += __shfl_xor(v0, off); v1 += __shfl_xor(v1, off);
             v2 += __shfl_xor(v2, off); v3 += __shfl_xor(v3, off);
         }
-        if (i == 0) {
-            const int x = cx_kk(q, h);
-            rec[2048 + 0 * 16 + x] = v0; rec[2048 + 1 * 16 + x] = v1;
-            rec[2048 + 2 * 16 + x] = v2; rec[2048 + 3 * 16 + x] = v3;
-        }
+        vsum[q][0] = v0; vsum[q][1] = v1; vsum[q][2] = v2; vsum[q][3] = v3;
     }
+    for (int w = 0; w < NWP; ++w) {
+        if (wsub == w) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int e = ((g & 3) + 8 * (g >> 2) + 4 * h) * 32 + i;
+                if (w == 0) { img[e] = R[g]; img[1024 + e] = Ps[g]; }
+                else { img[e] += R[g]; img[1024 + e] += Ps[g]; }
+            }
+            if (i == 0) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int x = cx_kk(q, h);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        if (w == 0) img[2048 + v * 16 + x] = vsum[q][v];
+                        else img[2048 + v * 16 + x] += vsum[q][v];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float* rec = ws + l.o_part_cx + (size_t)blockIdx.x * S * CX_REC;
+    for (int e = tid; e < S * CX_REC; e += NT) rec[e] = s_D[e];
     // E partial of the block
     double v = Eacc;
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -298,17 +315,6 @@ __global__ __launch_bounds__(NT) void k_elbo_cx(Lay l, const float* __restrict__
         for (int w = 0; w < NT / 64; ++w) s += dred[w];
         reinterpret_cast<double*>(ws + l.o_Epart)[blockIdx.x] = s;
     }
-}
-
-// totals per phase: tot[r][CX_REC] = sum over blocks and over the waves that worked on phase r
-__global__ __launch_bounds__(NT) void k_sum_records_cx(Lay l, float* __restrict__ ws) {
-    const int idx = blockIdx.x * NT + threadIdx.x;
-    if (idx >= l.S * CX_REC) return;
-    const int r = idx / CX_REC, e = idx - r * CX_REC;
-    double s = 0.0;
-    for (int b = 0; b < l.nblk_cx; ++b)
-        for (int w = r; w < 4; w += l.S) s += (double)ws[l.o_part_cx + ((size_t)b * 4 + w) * CX_REC + e];
-    ws[l.o_tot_cx + idx] = (float)s;
 }
 
 // raw gradients of the complex channel kernels from the per-phase totals
@@ -374,7 +380,7 @@ int launch_elbo_cx(const Lay& l, const float* y, float* ws, hipStream_t st) {
 
 void launch_finish_channel_cx(const Lay& l, float* ws, const double* scal, const float* grad_scale, float* g_h1, float* g_h2,
                               hipStream_t st) {
-    hipLaunchKernelGGL(k_sum_records_cx, dim3((l.S * CX_REC + NT - 1) / NT), dim3(NT), 0, st, l, ws);
+    launch_sum_records(l, ws + l.o_part_cx, l.S * CX_REC, l.nblk_cx, ws + l.o_sumstage, ws + l.o_tot_cx, st);
     const int n = 2 * l.L + 2 * l.L * l.L;
     hipLaunchKernelGGL(k_chain_channel_cx, dim3((n + NT - 1) / NT), dim3(NT), 0, st, l, (const float*)ws, scal, grad_scale, g_h1, g_h2);
 }

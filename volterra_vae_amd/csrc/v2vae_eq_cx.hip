@@ -160,24 +160,25 @@ __global__ __launch_bounds__(NT) void k_eq_bwd_cx(Lay l, const float* __restrict
             R11 = MFMA32(sig, xb, R11);
         }
     }
-    float* rec = ws + l.o_part_eqcx + ((size_t)blockIdx.x * 4 + wv) * 4096;
+    // fixed-order reduction of the four waves through LDS, then one record per block
+    __syncthreads();
+    float* img = sm;  // [4][1024]
+    for (int w = 0; w < 4; ++w) {
+        if (wv == w) {
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-        const int row = (g & 3) + 8 * (g >> 2) + 4 * h;
-        rec[0 * 1024 + row * 32 + j] = R00[g];
-        rec[1 * 1024 + row * 32 + j] = R01[g];
-        rec[2 * 1024 + row * 32 + j] = R10[g];
-        rec[3 * 1024 + row * 32 + j] = R11[g];
+            for (int g = 0; g < 16; ++g) {
+                const int e = ((g & 3) + 8 * (g >> 2) + 4 * h) * 32 + j;
+                if (w == 0) {
+                    img[e] = R00[g]; img[1024 + e] = R01[g]; img[2048 + e] = R10[g]; img[3072 + e] = R11[g];
+                } else {
+                    img[e] += R00[g]; img[1024 + e] += R01[g]; img[2048 + e] += R10[g]; img[3072 + e] += R11[g];
+                }
+            }
+        }
+        __syncthreads();
     }
-}
-
-__global__ __launch_bounds__(NT) void k_sum_records_eqcx(Lay l, float* __restrict__ ws) {
-    const int idx = blockIdx.x * NT + threadIdx.x;
-    if (idx >= 4096) return;
-    double s = 0.0;
-    const int nrec = l.nblk_eq * 4;
-    for (int b = 0; b < nrec; ++b) s += (double)ws[l.o_part_eqcx + (size_t)b * 4096 + idx];
-    ws[l.o_tot_eqcx + idx] = (float)s;
+    float* rec = ws + l.o_part_eqcx + (size_t)blockIdx.x * 4096;
+    for (int e = tid; e < 4096; e += NT) rec[e] = img[e];
 }
 
 __global__ __launch_bounds__(NT) void k_chain_equaliser_cx(Lay l, const float* __restrict__ ws, float* __restrict__ g_k1,
@@ -221,7 +222,7 @@ int launch_eq_bwd_cx(const Lay& l, const float* y, const float* gx, float* ws, h
 }
 
 void launch_finish_equaliser_cx(const Lay& l, float* ws, float* g_k1, float* g_k2, hipStream_t st) {
-    hipLaunchKernelGGL(k_sum_records_eqcx, dim3(4096 / NT), dim3(NT), 0, st, l, ws);
+    launch_sum_records(l, ws + l.o_part_eqcx, 4096, l.nblk_eq, ws + l.o_sumstage, ws + l.o_tot_eqcx, st);
     const int n = 2 * l.l1 + 2 * l.l2 * l.l2;
     hipLaunchKernelGGL(k_chain_equaliser_cx, dim3((n + NT - 1) / NT), dim3(NT), 0, st, l, (const float*)ws, g_k1, g_k2);
 }

@@ -110,6 +110,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
         l.nk1 = l.ns * l.ns * l.l1;
         if (l.nk1 > 4 * NT) return V2VAE_ESIZE;
         int64_t fl = (int64_t)l.ns * l.tile_len + (int64_t)l.ns * EQ_TB + SCRATCH_F;
+        if (fl < 4096 + 64) fl = 4096 + 64;  // the matrix-core backward reduces its four waves through a 16 KB image
         if (fl * 4 > LDS_BUDGET) return V2VAE_ESIZE;
         l.lds_eq = (int)(fl * 4);
     }
@@ -154,11 +155,19 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     l.o_tot_sym = take(l.rec_sym);
     l.o_cxH = take((int64_t)l.S * 2 * 256);
     l.o_cxh1 = take((int64_t)l.S * 2 * 16);
-    l.o_part_cx = take(l.use_cx ? (int64_t)l.nblk_cx * 4 * CX_REC : 0);
+    l.o_part_cx = take(l.use_cx ? (int64_t)l.nblk_cx * l.S * CX_REC : 0);
     l.o_tot_cx = take((int64_t)l.S * CX_REC);
     l.o_eqcxA = take(l.use_eqcx ? (int64_t)2 * l.eqcx_steps * 64 : 0);
-    l.o_part_eqcx = take(l.use_eqcx ? (int64_t)l.nblk_eq * 4 * 4096 : 0);
+    l.o_part_eqcx = take(l.use_eqcx ? (int64_t)l.nblk_eq * 4096 : 0);
     l.o_tot_eqcx = take(l.use_eqcx ? 4096 : 0);
+    {
+        int64_t mx = l.rec_elbo;
+        if (l.rec_eq > mx) mx = l.rec_eq;
+        if (l.rec_sym > mx) mx = l.rec_sym;
+        if (l.S * CX_REC > mx) mx = l.S * CX_REC;
+        if (4096 > mx) mx = 4096;
+        l.o_sumstage = take((int64_t)SUM_CHUNKS * mx);
+    }
     l.o_Epart = take(2 * (int64_t)(l.nblk_elbo > l.nblk_cx ? l.nblk_elbo : l.nblk_cx));
     l.o_KLpart = take(2 * (int64_t)l.nblk_sym);
     l.total_floats = o;
@@ -988,12 +997,30 @@ __global__ void k_finalize_scalars(double W, double* __restrict__ scal) {
     }
 }
 
-__global__ __launch_bounds__(NT) void k_sum_records(const float* __restrict__ part, int rec, int nblk, float* __restrict__ tot) {
+// records [first, first + per) of `part` summed into out[blockIdx.y][.] (fixed order, double accumulation)
+__global__ __launch_bounds__(NT) void k_sum_records(const float* __restrict__ part, int rec, int nrec, int per,
+                                                    float* __restrict__ out) {
     const int i = blockIdx.x * NT + threadIdx.x;
     if (i >= rec) return;
+    const int first = blockIdx.y * per;
+    const int last = first + per < nrec ? first + per : nrec;
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)part[(size_t)b * rec + i];
-    tot[i] = (float)s;
+    for (int b = first; b < last; ++b) s += (double)part[(size_t)b * rec + i];
+    out[(size_t)blockIdx.y * rec + i] = (float)s;
+}
+
+void launch_sum_records(const Lay& l, const float* part, int rec, int nrec, float* stage, float* tot, hipStream_t st) {
+    (void)l;
+    if (rec <= 0) return;
+    const int gx = (rec + NT - 1) / NT;
+    if (nrec <= SUM_CHUNKS) {
+        hipLaunchKernelGGL(k_sum_records, dim3(gx, 1), dim3(NT), 0, st, part, rec, nrec, nrec, tot);
+        return;
+    }
+    const int per = (nrec + SUM_CHUNKS - 1) / SUM_CHUNKS;
+    const int chunks = (nrec + per - 1) / per;
+    hipLaunchKernelGGL(k_sum_records, dim3(gx, chunks), dim3(NT), 0, st, part, rec, nrec, per, stage);
+    hipLaunchKernelGGL(k_sum_records, dim3(gx, 1), dim3(NT), 0, st, (const float*)stage, rec, chunks, chunks, tot);
 }
 
 // dE/dHs[o][a][b] on original stacked taps from the per-phase compact totals
@@ -1314,22 +1341,19 @@ int v2vae_finish_grads(const v2vae_problem* p, void* ws, const double* scal, con
     if ((which & 1) && l.use_cx) {
         launch_finish_channel_cx(l, w, scal, grad_scale, g_h1, g_h2, st);
     } else if (which & 1) {
-        hipLaunchKernelGGL(k_sum_records, dim3((l.rec_elbo + NT - 1) / NT), dim3(NT), 0, st, w + l.o_part_elbo, l.rec_elbo,
-                           l.nblk_elbo, w + l.o_tot_elbo);
+        launch_sum_records(l, w + l.o_part_elbo, l.rec_elbo, l.nblk_elbo, w + l.o_sumstage, w + l.o_tot_elbo, st);
         const int n = l.ns * l.L + l.ns * l.L * l.L;
         hipLaunchKernelGGL(k_chain_channel, dim3((n + NT - 1) / NT), dim3(NT), 0, st, l, (const float*)w, scal, grad_scale, g_h1, g_h2);
     }
     if (which & 2) {
-        hipLaunchKernelGGL(k_sum_records, dim3((l.rec_sym + NT - 1) / NT), dim3(NT), 0, st, w + l.o_part_sym, l.rec_sym,
-                           l.nblk_sym, w + l.o_tot_sym);
+        launch_sum_records(l, w + l.o_part_sym, l.rec_sym, l.nblk_sym, w + l.o_sumstage, w + l.o_tot_sym, st);
         if (g_scaling)
             hipLaunchKernelGGL(k_copy, dim3((l.rec_sym + NT - 1) / NT), dim3(NT), 0, st, (const float*)(w + l.o_tot_sym), g_scaling, l.rec_sym);
     }
     if ((which & 4) && l.use_eqcx) {
         launch_finish_equaliser_cx(l, w, g_k1, g_k2, st);
     } else if (which & 4) {
-        hipLaunchKernelGGL(k_sum_records, dim3((l.rec_eq + NT - 1) / NT), dim3(NT), 0, st, w + l.o_part_eq, l.rec_eq,
-                           l.nblk_eq, w + l.o_tot_eq);
+        launch_sum_records(l, w + l.o_part_eq, l.rec_eq, l.nblk_eq, w + l.o_sumstage, w + l.o_tot_eq, st);
         const int n = l.ns * l.l1 + l.ns * l.l2 * l.l2;
         hipLaunchKernelGGL(k_chain_equaliser, dim3((n + NT - 1) / NT), dim3(NT), 0, st, l, (const float*)w, g_k1, g_k2);
     }

@@ -27,6 +27,7 @@ constexpr int CX_TWB = 128;          // windows per phase per block tile
 constexpr int CX_MS = CX_TWB + 48;   // staged symbol slots per block tile
 constexpr int CX_TP = 33;            // row pitch of the per-wave transposing buffer
 constexpr int CX_REC = 2112;         // floats per wave record: R 32x32, Ps 32x32, 4 vectors of 16
+constexpr int SUM_CHUNKS = 32;       // first-stage groups of the two-stage partial-record sums
 constexpr int CX_BLOCKS = 256;       // one workgroup per CU (the LDS image takes most of a CU)
 
 struct Lay {
@@ -50,6 +51,7 @@ struct Lay {
     // matrix-core equaliser path
     int use_eqcx, eqcx_lk, eqcx_steps;
     int64_t o_eqcxA, o_part_eqcx, o_tot_eqcx;
+    int64_t o_sumstage;      // [SUM_CHUNKS][largest record] staging of the two-stage record sums
     // record sizes of the per-workgroup partial sums (floats)
     int rec_elbo, rec_eq, rec_sym;
     // workspace offsets in floats
@@ -68,6 +70,9 @@ int make_layout(const v2vae_problem* p, Lay* out);
 int launch_elbo_cx(const Lay& l, const float* y, float* ws, hipStream_t st);
 void launch_finish_channel_cx(const Lay& l, float* ws, const double* scal, const float* grad_scale, float* g_h1, float* g_h2,
                               hipStream_t st);
+
+// two-stage deterministic sum of nrec records of `rec` floats: tot[e] = sum_b part[b][e]  (v2vae_kernels.hip)
+void launch_sum_records(const Lay& l, const float* part, int rec, int nrec, float* stage, float* tot, hipStream_t st);
 
 // v2vae_eq_cx.hip
 int launch_prep_eqcx(const Lay& l, const float* k1, const float* k2, float* ws, hipStream_t st);
