@@ -317,6 +317,478 @@ __global__ __launch_bounds__(NT) void k_elbo_cx(Lay l, const float* __restrict__
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Second generation: 8 waves per workgroup (two per SIMD, so one wave's per-tap algebra overlaps the other's MFMA
+// chain), constant A operands in LDS, block tiles of 256 windows per phase, and an LDS-lean gather: each wave sums
+// its own 32 x Le tile of per-(window, tap) gradients along the anti-diagonals (symbol = window + tap) into a
+// 47-entry partial per (phase, subtile); the block then adds the <= 2 x S partials that cover a symbol in a fixed order.
+// The s s^T accumulation is not done here at all: it is a sum of lagged products along the symbol axis
+// (k_psum_cx + psum_value below), O(Le) instead of O(Le^2) per window.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int CX2_TWB = 256;
+constexpr int CX2_MS = CX2_TWB + 48;
+constexpr int CX2_NU = CX2_TWB / 32;
+constexpr int CX2_NSIG = 64;  // anti-diagonal entries kept per unit (47 used; 64 keeps the store branch-free)
+
+template <int S, int NW>
+__global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __restrict__ y, float* __restrict__ ws) {
+    extern __shared__ float sm[];
+    constexpr int TWB = CX2_TWB, MS = CX2_MS, TP = CX_TP, NU = CX2_NU, NSIG = CX2_NSIG;
+    constexpr int NWP = NW / S;
+    constexpr int CX2_NT = NW * 64;
+    // one staging buffer: moments as float4 (mean, variance, 3rd central moment, 4th cumulant) [2][MS], the means
+    // again as plain arrays [2][MS] (MFMA operands want unit stride), s = v_a + v_b [MS], y' [2][S][TWB]
+    constexpr int STG = 11 * MS + 2 * S * TWB;
+    float* s_stage = sm;                      // [2][STG] double buffered
+    float* s_A = s_stage + 2 * STG;           // [S][40][64]  A operands: steps 0-15 H X, 16-23 (H.H) s, 24-39 H w
+    float* s_c = s_A + S * 40 * 64;           // [S][4][16]   h1r, h1i, diag Hr, diag Hi
+    float* s_T = s_c + S * 64;                // [8 waves][32 * TP]  transposing buffer of rho / sigma
+    float* s_B = s_T + NW * 32 * TP;           // [NW waves][16][64] anti-diagonal buffer: columns 16..47 live, the rest stays 0
+    float* s_P = s_B + NW * 1024;              // [S][NU][6][NSIG]
+    __shared__ double dred[CX2_NT / 64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int r = wv / NWP, wsub = wv % NWP;
+    float* Tb = s_T + wv * 32 * TP;
+    float* Bd = s_B + wv * 1024;
+    const float* __restrict__ mom = ws + l.o_mom;
+    float* __restrict__ gmom = ws + l.o_gmom;
+    const int64_t own_hi = l.own_lo + l.own_cnt, sym_hi = l.sym_lo + l.sym_cnt;
+    const int TS = TWB - l.kmax;
+    const int cj = i >> 4, yj = i & 15;
+
+    // ---- constants of every phase into LDS
+    for (int idx = tid; idx < S * 40 * 64; idx += CX2_NT) {
+        const int ln = idx & 63, s = (idx >> 6) % 40, rr = idx / (40 * 64);
+        const int jj = ln & 31, hh = ln >> 5, cjj = jj >> 4, yjj = jj & 15;
+        const float* Hr = ws + l.o_cxH + (size_t)(rr * 2 + 0) * 256;
+        const float* Hi = ws + l.o_cxH + (size_t)(rr * 2 + 1) * 256;
+        float v;
+        if (s < 16) {          // [[Hr, Hi], [-Hi, Hr]], k = 2 s + h
+            const int k = 2 * s + hh, ck = k >> 4, xk = k & 15;
+            const float a = Hr[xk * 16 + yjj], b = Hi[xk * 16 + yjj];
+            v = ck == 0 ? (cjj == 0 ? a : b) : (cjj == 0 ? -b : a);
+        } else if (s < 24) {   // |H|^2 rows 0..15, k = 2 (s - 16) + h
+            const int x = 2 * (s - 16) + hh;
+            const float a = Hr[yjj * 16 + x], b = Hi[yjj * 16 + x];
+            v = cjj == 0 ? a * a + b * b : 0.f;
+        } else {               // [[Hr, -Hi], [Hi, Hr]], k-slot <-> row ((s-24) >> 3, kk((s-24) & 7, h))
+            const int s2 = s - 24, ck = s2 >> 3, xk = cx_kk(s2 & 7, hh);
+            const float a = Hr[xk * 16 + yjj], b = Hi[xk * 16 + yjj];
+            v = ck == 0 ? (cjj == 0 ? a : -b) : (cjj == 0 ? b : a);
+        }
+        s_A[idx] = v;
+    }
+    for (int idx = tid; idx < S * 64; idx += CX2_NT) {
+        const int rr = idx / 64, q = (idx >> 4) & 3, x = idx & 15;
+        const float* Hr = ws + l.o_cxH + (size_t)(rr * 2 + 0) * 256;
+        const float* Hi = ws + l.o_cxH + (size_t)(rr * 2 + 1) * 256;
+        s_c[idx] = q == 0 ? ws[l.o_cxh1 + (rr * 2 + 0) * 16 + x] : q == 1 ? ws[l.o_cxh1 + (rr * 2 + 1) * 16 + x]
+                 : q == 2 ? Hr[x * 16 + x] : Hi[x * 16 + x];
+    }
+    for (int idx = tid; idx < NW * 1024; idx += CX2_NT) s_B[idx] = 0.f;
+    const float* Aop = s_A + (size_t)r * 40 * 64 + lane;
+    // per-tap constants stay in LDS (all lanes of a half read one address: a broadcast, no bank conflict)
+    const float* cst = s_c + r * 64 + 4 * h;
+#define C_HR(q) cst[0 * 16 + ((q) & 3) + 8 * ((q) >> 2)]
+#define C_HI(q) cst[1 * 16 + ((q) & 3) + 8 * ((q) >> 2)]
+#define C_DR(q) cst[2 * 16 + ((q) & 3) + 8 * ((q) >> 2)]
+#define C_DI(q) cst[3 * 16 + ((q) & 3) + 8 * ((q) >> 2)]
+    __syncthreads();
+    float dd_sum[S];
+#pragma unroll
+    for (int rr = 0; rr < S; ++rr) {
+        float t = 0.f;
+        for (int kk = 0; kk < l.LE; ++kk) {
+            const float dr = s_c[rr * 64 + 2 * 16 + kk], di = s_c[rr * 64 + 3 * 16 + kk];
+            t += dr * dr + di * di;
+        }
+        dd_sum[rr] = t;
+    }
+
+#ifdef V2VAE_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+#define STAMP(k)                                                        \
+    do {                                                                \
+        __builtin_amdgcn_sched_barrier(0);                              \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                             \
+        st_acc[k] += now_ - st_last;                                    \
+        st_last = now_;                                                 \
+        __builtin_amdgcn_sched_barrier(0);                              \
+    } while (0)
+#else
+#define STAMP(k)
+#endif
+    f32x16 R;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) R[g] = 0.f;
+    float ghr[8], ghi[8], gdr[8], gdi[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { ghr[q] = 0.f; ghi[q] = 0.f; gdr[q] = 0.f; gdi[q] = 0.f; }
+    double Eacc = 0.0;
+
+    // staging of one block tile through registers, so that the loads of tile n + 1 are in flight while tile n is
+    // being computed: thread t carries symbol slots t, t + NT, ... (all eight moments of a slot) and y' slots likewise
+    constexpr int NSL = (MS + CX2_NT - 1) / CX2_NT;
+    constexpr int NYW = (2 * S * TWB + CX2_NT - 1) / CX2_NT;
+    float4 prea[NSL], preb[NSL];
+    float prey[NYW];
+    auto stage_load = [&](int tile) {
+        const int64_t s0 = l.own_lo + (int64_t)tile * TS;
+        const int64_t s1 = (s0 + TS < own_hi) ? s0 + TS : own_hi;
+        const int64_t tbase = s0 - l.kmax;
+#pragma unroll
+        for (int u = 0; u < NSL; ++u) {
+            const int ms = tid + u * CX2_NT;
+            const int64_t m = tbase + ms;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+            if (ms < MS && m >= l.sym_lo && m < sym_hi) {
+                const float* g = mom + (m - l.sym_lo);
+                const int64_t st = l.sym_cnt;
+                a = make_float4(g[0], g[st], g[2 * st], g[3 * st]);
+                b = make_float4(g[4 * st], g[5 * st], g[6 * st], g[7 * st]);
+            }
+            prea[u] = a; preb[u] = b;
+        }
+#pragma unroll
+        for (int u = 0; u < NYW; ++u) {
+            const int e = tid + u * CX2_NT;
+            const int o = e / (S * TWB), rem = e - o * S * TWB;
+            const int rr = rem / TWB, slot = rem - rr * TWB;
+            const int64_t t = tbase + slot, n = t * S + rr;
+            float v = 0.f;
+            if (e < 2 * S * TWB && t < s1 && n >= 0 && n < l.W) {
+                const int64_t loc = l.pre + n - l.y_lo;
+                if (loc >= 0 && loc < l.y_len) v = y[(int64_t)o * l.y_len + loc];
+            }
+            prey[u] = v;
+        }
+    };
+    auto stage_store = [&](float* dst) {
+        float4* d4 = reinterpret_cast<float4*>(dst);
+#pragma unroll
+        for (int u = 0; u < NSL; ++u) {
+            const int ms = tid + u * CX2_NT;
+            if (ms < MS) {
+                d4[ms] = prea[u];
+                d4[MS + ms] = preb[u];
+                dst[8 * MS + ms] = prea[u].x;
+                dst[9 * MS + ms] = preb[u].x;
+                dst[10 * MS + ms] = prea[u].y + preb[u].y;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NYW; ++u) {
+            const int e = tid + u * CX2_NT;
+            if (e < 2 * S * TWB) dst[11 * MS + e] = prey[u];
+        }
+    };
+    int buf = 0;
+    if (blockIdx.x < l.ntile_cx) { stage_load(blockIdx.x); stage_store(s_stage); }
+    __syncthreads();
+
+    for (int tile = blockIdx.x; tile < l.ntile_cx; tile += gridDim.x) {
+        const int64_t s0 = l.own_lo + (int64_t)tile * TS;
+        const int64_t s1 = (s0 + TS < own_hi) ? s0 + TS : own_hi;
+        const int64_t tbase = s0 - l.kmax;
+        const float4* s_m4 = reinterpret_cast<const float4*>(s_stage + buf * STG);   // [2][MS]
+        const float* s_mu = s_stage + buf * STG + 8 * MS;                             // [2][MS]
+        const float* s_S = s_mu + 2 * MS;
+        const float* s_yw = s_S + MS;
+        const bool more = tile + (int)gridDim.x < l.ntile_cx;
+        if (more) stage_load(tile + gridDim.x);
+        STAMP(0);
+
+        for (int sub = wsub; sub < NU; sub += NWP) {
+            const int tsl = sub * 32;
+            const int64_t t = tbase + tsl + i, n = t * S + r;
+            const bool valid = (t < s1) && n >= 0 && n < l.W;
+            const bool own = valid && t >= s0;
+            const float mv = valid ? 1.f : 0.f, mo = own ? 1.f : 0.f;
+
+            f32x16 U, TT;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { U[g] = 0.f; TT[g] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int k = 2 * s + h;
+                const float b = s_mu[(k >> 4) * MS + tsl + i + (k & 15)];
+                U = MFMA32(Aop[s * 64], b, U);
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const float b = s_S[tsl + i + 2 * s + h];
+                TT = MFMA32(Aop[(16 + s) * 64], b, TT);
+            }
+
+            STAMP(1);
+            float zP[8], zQ[8], al[8], be[8], zz[8], dvv[8];
+            float a0 = 0.f, a1 = 0.f, q0 = 0.f, q1 = 0.f, sd0 = 0.f, sd1 = 0.f, vs = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int slot = tsl + i + cx_kk(q, h);
+                const float P = U[q], Q = U[q + 8], T = TT[q];
+                const float4 m4a = s_m4[slot], m4b = s_m4[MS + slot];
+                const float ma = m4a.x, va = m4a.y, ka = m4a.z, ga = m4a.w;
+                const float mb = m4b.x, vb = m4b.y, kb = m4b.z, gb = m4b.w;
+                const float hr = C_HR(q), hi = C_HI(q), dr = C_DR(q), di = C_DI(q);
+                const float zp = fmaf(2.f, P, hr), zq = fmaf(2.f, Q, hi);
+                a0 += hr * ma - hi * mb;
+                a1 += hi * ma + hr * mb;
+                q0 += ma * P - mb * Q;
+                q1 += ma * Q + mb * P;
+                const float Sv = va + vb, dv = va - vb, gs = ga + gb;
+                sd0 = fmaf(dv, dr, sd0);
+                sd1 = fmaf(dv, di, sd1);
+                const float z2 = zp * zp + zq * zq;
+                const float ca = dr * zp + di * zq, cb = dr * zq - di * zp;
+                vs += Sv * z2 + 2.f * Sv * T + 2.f * (ka * ca + kb * cb) + gs * (dr * dr + di * di);
+                al[q] = 2.f * Sv * zp + 2.f * (ka * dr - kb * di);
+                be[q] = 2.f * Sv * zq + 2.f * (ka * di + kb * dr);
+                zP[q] = zp; zQ[q] = zq;
+                zz[q] = z2 + 4.f * T;
+                dvv[q] = dv;
+                gdr[q] += mo * (2.f * (ka * zp + kb * zq) + 2.f * gs * dr);
+                gdi[q] += mo * (2.f * (ka * zq - kb * zp) + 2.f * gs * di);
+            }
+            a0 += __shfl_xor(a0, 32); a1 += __shfl_xor(a1, 32);
+            q0 += __shfl_xor(q0, 32); q1 += __shfl_xor(q1, 32);
+            sd0 += __shfl_xor(sd0, 32); sd1 += __shfl_xor(sd1, 32);
+            vs += __shfl_xor(vs, 32);
+            const float y0 = s_yw[(0 * S + r) * TWB + tsl + i], y1 = s_yw[(1 * S + r) * TWB + tsl + i];
+            float e0 = a0 + q0 + sd0 - y0, e1 = a1 + q1 + sd1 - y1;
+            if (own && h == 0) Eacc += (double)(e0 * e0 + e1 * e1 + vs);
+            e0 *= mv; e1 *= mv;
+
+            STAMP(2);
+            f32x16 HW;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) HW[g] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) HW = MFMA32(Aop[(24 + s) * 64], s < 8 ? al[s & 7] : be[s & 7], HW);
+
+            // ---- anti-diagonal sums of the moment gradients, two quantities per round through the wave's buffer
+            STAMP(3);
+            // ---- anti-diagonal sums of the moment gradients (symbol = window + tap), one quantity per round through
+            //      the wave's zero-padded buffer.  LDS instructions of one wave execute in program order, so lanes may
+            //      read what other lanes of the same wave wrote earlier; wave_barrier only pins the compiler's ordering.
+            float* Pu = s_P + ((size_t)(r * NU + sub) * 6) * NSIG;
+#pragma unroll
+            for (int round = 0; round < 6; ++round) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int x = cx_kk(q, h);
+                    const float zp = zP[q], zq = zQ[q], dr = C_DR(q), di = C_DI(q);
+                    float d;
+                    if (round == 0) d = 2.f * (e0 * zp + e1 * zq) + 2.f * HW[q];
+                    else if (round == 1) d = 2.f * (e1 * zp - e0 * zq) + 2.f * HW[q + 8];
+                    else if (round == 2) d = zz[q] + 2.f * (e0 * dr + e1 * di);
+                    else if (round == 3) d = zz[q] - 2.f * (e0 * dr + e1 * di);
+                    else if (round == 4) d = 2.f * (dr * zp + di * zq);
+                    else d = 2.f * (dr * zq - di * zp);
+                    Bd[x * 64 + 16 + i] = mv * d;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (lane < 48) {
+                    float sa = 0.f;
+#pragma unroll
+                    for (int x = 0; x < 16; ++x) sa += Bd[x * 63 + 16 + lane];   // row x, column 16 + (lane - x)
+                    Pu[round * NSIG + lane] = sa;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+
+            STAMP(4);
+            // ---- rho / sigma (transposed through LDS), vector gradients
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int x = cx_kk(q, h);
+                const int slot = tsl + i + x;
+                const float ma = s_mu[slot], mb = s_mu[MS + slot];
+                const float gr = 2.f * (e0 * ma + e1 * mb), gi = 2.f * (e1 * ma - e0 * mb);
+                ghr[q] += mo * (gr + al[q]);
+                ghi[q] += mo * (gi + be[q]);
+                gdr[q] += mo * 2.f * e0 * dvv[q];
+                gdi[q] += mo * 2.f * e1 * dvv[q];
+                Tb[i * TP + x] = mo * (gr + 2.f * al[q]);
+                Tb[i * TP + 16 + x] = mo * (gi + 2.f * be[q]);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int w = 2 * s + h;
+                const float a = Tb[w * TP + i];
+                const float b = s_mu[cj * MS + tsl + w + yj];
+                R = MFMA32(a, b, R);
+            }
+            __builtin_amdgcn_wave_barrier();
+            STAMP(5);
+        }
+        if (more) stage_store(s_stage + (buf ^ 1) * STG);
+        buf ^= 1;
+        __syncthreads();
+        // ---- gather: symbol slot ms = kmax + ml is covered by subtile ms / 32 and, if ms % 32 <= Le - 2, by the one before
+        for (int idx = tid; idx < 2 * TS; idx += CX2_NT) {
+            const int c = idx / TS, ml = idx - c * TS;
+            const int64_t m = s0 + ml;
+            if (m < s1) {
+                const int ms = ml + l.kmax;
+                const int sub_hi = ms >> 5, sg_hi = ms & 31;
+                const bool two = (sg_hi + 32 < 32 + l.LE - 1) && sub_hi > 0;
+                float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+                // every window that holds this symbol exists: (m - kmax) * S >= 0 and m * S + S - 1 < W
+                const bool interior = (m - l.kmax) >= 0 && (m * S + S - 1) < l.W;
+                for (int rr = 0; rr < S; ++rr) {
+                    if (two) {
+                        const float* P = s_P + ((size_t)(rr * NU + sub_hi - 1) * 6) * NSIG + sg_hi + 32;
+                        g0 += P[(0 + c) * NSIG]; g1 += P[(2 + c) * NSIG]; g2 += P[(4 + c) * NSIG];
+                    }
+                    if (sub_hi < NU) {
+                        const float* P = s_P + ((size_t)(rr * NU + sub_hi) * 6) * NSIG + sg_hi;
+                        g0 += P[(0 + c) * NSIG]; g1 += P[(2 + c) * NSIG]; g2 += P[(4 + c) * NSIG];
+                    }
+                    if (interior) g3 += dd_sum[rr];
+                    else
+                        for (int kk = 0; kk < l.LE; ++kk) {
+                            const int64_t t = m - kk, n = t * S + rr;
+                            if (n >= 0 && n < l.W) {
+                                const float dr = s_c[rr * 64 + 2 * 16 + kk], di = s_c[rr * 64 + 3 * 16 + kk];
+                                g3 += dr * dr + di * di;
+                            }
+                        }
+                }
+                float* gp = gmom + (int64_t)c * 4 * l.sym_cnt + (m - l.sym_lo);
+                gp[0] = g0; gp[l.sym_cnt] = g1; gp[2 * l.sym_cnt] = g2; gp[3 * l.sym_cnt] = g3;
+            }
+        }
+        __syncthreads();
+        STAMP(6);
+    }
+#ifdef V2VAE_STAMPS
+    if (lane == 0) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(ws + l.o_sumstage);  // free until the record sums run
+        for (int k = 0; k < 8; ++k) dbg[((size_t)blockIdx.x * NW + wv) * 8 + k] = st_acc[k];
+    }
+#endif
+
+    // ---- one record per (block, phase); Ps block of the record is left zero (filled from the lagged sums later)
+    float* img = s_T + (size_t)r * CX_REC;  // NW * 32 * TP >= 4224 floats >= S * CX_REC
+    float vsum[8][4];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        float v0 = ghr[q], v1 = ghi[q], v2 = gdr[q], v3 = gdi[q];
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) {
+            v0 += __shfl_xor(v0, off); v1 += __shfl_xor(v1, off);
+            v2 += __shfl_xor(v2, off); v3 += __shfl_xor(v3, off);
+        }
+        vsum[q][0] = v0; vsum[q][1] = v1; vsum[q][2] = v2; vsum[q][3] = v3;
+    }
+    for (int w = 0; w < NWP; ++w) {
+        if (wsub == w) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int e = ((g & 3) + 8 * (g >> 2) + 4 * h) * 32 + i;
+                if (w == 0) { img[e] = R[g]; img[1024 + e] = 0.f; }
+                else img[e] += R[g];
+            }
+            if (i == 0) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int x = cx_kk(q, h);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        if (w == 0) img[2048 + v * 16 + x] = vsum[q][v];
+                        else img[2048 + v * 16 + x] += vsum[q][v];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float* rec = ws + l.o_part_cx + (size_t)blockIdx.x * S * CX_REC;
+    for (int e = tid; e < S * CX_REC; e += CX2_NT) rec[e] = s_T[e];
+    double v = Eacc;
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();
+    if (lane == 0) dred[wv] = v;
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int w = 0; w < CX2_NT / 64; ++w) s += dred[w];
+        reinterpret_cast<double*>(ws + l.o_Epart)[blockIdx.x] = s;
+    }
+}
+
+// Lagged products of s = v_a + v_b over the owned symbols: C[d] = sum_m s[m] s[m + d], d = 0..15.
+__device__ __forceinline__ float cx_s_at(const Lay& l, const float* __restrict__ mom, int64_t m) {
+    if (m < l.sym_lo || m >= l.sym_lo + l.sym_cnt) return 0.f;
+    return mom[(int64_t)1 * l.sym_cnt + (m - l.sym_lo)] + mom[(int64_t)5 * l.sym_cnt + (m - l.sym_lo)];
+}
+
+__global__ __launch_bounds__(NT) void k_psum_cx(Lay l, float* __restrict__ ws) {
+    __shared__ double red[NT / 64][16];
+    const float* __restrict__ mom = ws + l.o_mom;
+    double acc[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) acc[d] = 0.0;
+    for (int64_t j = (int64_t)blockIdx.x * NT + threadIdx.x; j < l.own_cnt; j += (int64_t)gridDim.x * NT) {
+        const int64_t m = l.own_lo + j;
+        const float s0 = cx_s_at(l, mom, m);
+#pragma unroll
+        for (int d = 0; d < 16; ++d)
+            if (d <= l.kmax) acc[d] += (double)(s0 * cx_s_at(l, mom, m + d));
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+        double v = acc[d];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) red[wv][d] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        double s = 0.0;
+        for (int w = 0; w < NT / 64; ++w) s += red[w][threadIdx.x];
+        reinterpret_cast<double*>(ws + l.o_psum_part)[(size_t)blockIdx.x * 16 + threadIdx.x] = s;
+    }
+}
+
+__global__ __launch_bounds__(NT) void k_psum_finish_cx(Lay l, float* __restrict__ ws) {
+    __shared__ double red[16][17];
+    const int d = threadIdx.x & 15, c = threadIdx.x >> 4;  // 16 lags x 16 chunks
+    const double* part = reinterpret_cast<const double*>(ws + l.o_psum_part);
+    double s = 0.0;
+    for (int b = c; b < l.nblk_psum; b += 16) s += part[(size_t)b * 16 + d];
+    red[c][d] = s;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
+        reinterpret_cast<double*>(ws + l.o_psum_tot)[threadIdx.x] = t;
+    }
+}
+
+// sum over the owned, valid windows t of phase r of s[t + a] s[t + b]
+__device__ __forceinline__ float psum_value(const Lay& l, const float* __restrict__ ws, int r, int a, int b) {
+    const float* __restrict__ mom = ws + l.o_mom;
+    const int kk = a < b ? a : b, d = a < b ? b - a : a - b;
+    const int64_t lo = l.own_lo, hi = l.own_lo + l.own_cnt;
+    const int64_t Tr = (l.W - 1 - r >= 0) ? (l.W - 1 - r) / l.S + 1 : 0;
+    const int64_t br = hi < Tr ? hi : Tr;
+    if (br <= lo) return 0.f;
+    double v = reinterpret_cast<const double*>(ws + l.o_psum_tot)[d];
+    auto c = [&](int64_t m) { return (double)(cx_s_at(l, mom, m) * cx_s_at(l, mom, m + d)); };
+    for (int64_t m = lo; m < lo + kk; ++m) v -= c(m);
+    const int64_t last = br - 1 + kk;
+    if (last >= hi) { for (int64_t m = hi; m <= last; ++m) v += c(m); }
+    else { for (int64_t m = last + 1; m < hi; ++m) v -= c(m); }
+    return (float)v;
+}
+
 // raw gradients of the complex channel kernels from the per-phase totals
 __global__ __launch_bounds__(NT) void k_chain_channel_cx(Lay l, const float* __restrict__ ws, const double* __restrict__ scal,
                                                          const float* __restrict__ grad_scale, float* __restrict__ g_h1,
@@ -352,7 +824,7 @@ __global__ __launch_bounds__(NT) void k_chain_channel_cx(Lay l, const float* __r
                 const float* Hp = ws + l.o_cxH + (size_t)(ri * 2 + p) * 256;
                 auto G = [&](int a, int b) {
                     float g = (p == 0) ? Rm[a * 32 + b] + Rm[(16 + a) * 32 + 16 + b] : Rm[(16 + a) * 32 + b] - Rm[a * 32 + 16 + b];
-                    g += 4.f * Hp[a * 16 + b] * Pm[a * 32 + b];
+                    g += 4.f * Hp[a * 16 + b] * (l.cx_gen == 2 ? psum_value(l, ws, ri, a, b) : Pm[a * 32 + b]);
                     if (a == b) g += tot[2048 + (2 + p) * 16 + a];
                     return g;
                 };
@@ -366,6 +838,20 @@ __global__ __launch_bounds__(NT) void k_chain_channel_cx(Lay l, const float* __r
 int launch_elbo_cx(const Lay& l, const float* y, float* ws, hipStream_t st) {
     const int lds = l.lds_cx;
     hipError_t e = hipSuccess;
+    if (l.cx_gen == 2) {
+        hipLaunchKernelGGL(k_psum_cx, dim3(l.nblk_psum), dim3(NT), 0, st, l, ws);
+        hipLaunchKernelGGL(k_psum_finish_cx, dim3(1), dim3(NT), 0, st, l, ws);
+#define V2VAE_LAUNCH_CX2(SS, NWV)                                                                                          \
+    do {                                                                                                                   \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_elbo_cx2<SS, NWV>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        if (e != hipSuccess) return V2VAE_ELAUNCH;                                                                         \
+        hipLaunchKernelGGL((k_elbo_cx2<SS, NWV>), dim3(l.nblk_cx), dim3(NWV * 64), lds, st, l, y, ws);                      \
+    } while (0)
+        if (l.cx_waves == 8) { if (l.S == 1) V2VAE_LAUNCH_CX2(1, 8); else V2VAE_LAUNCH_CX2(2, 8); }
+        else { if (l.S == 1) V2VAE_LAUNCH_CX2(1, 4); else V2VAE_LAUNCH_CX2(2, 4); }
+#undef V2VAE_LAUNCH_CX2
+        return V2VAE_OK;
+    }
     if (l.S == 1) {
         if (lds > 64 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_elbo_cx<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return V2VAE_ELAUNCH;

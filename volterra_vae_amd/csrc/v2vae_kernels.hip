@@ -120,12 +120,20 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     }
     // ---- matrix-core ELBO path: complex model, <= 16 active taps per stream and phase, S in {1, 2}
     l.use_cx = (l.mode == 1 && l.LE <= 16 && l.S <= 2 && getenv("V2VAE_FORCE_GENERIC") == nullptr) ? 1 : 0;
+    l.cx_gen = getenv("V2VAE_CX_GEN1") ? 1 : 2;
+    l.cx_waves = getenv("V2VAE_CX_WAVES4") ? 4 : 8;
     {
-        const int ts = CX_TWB - l.kmax;
+        const int twb = l.cx_gen == 2 ? 256 : CX_TWB;
+        const int ts = twb - l.kmax;
         l.ntile_cx = (int)((l.own_cnt + ts - 1) / ts);
         l.nblk_cx = l.ntile_cx < CX_BLOCKS ? l.ntile_cx : CX_BLOCKS;
-        l.lds_cx = (8 * CX_MS + CX_MS + 2 * l.S * CX_TWB + l.S * 6 * 16 * CX_TWB + 4 * 32 * CX_TP) * 4;
+        if (l.cx_gen == 2)
+            l.lds_cx = (2 * (11 * (256 + 48) + 2 * l.S * 256) + l.S * 40 * 64 + l.S * 64 + 8 * 32 * CX_TP + 8 * 1024 + l.S * 8 * 6 * 64) * 4;
+        else
+            l.lds_cx = (8 * CX_MS + CX_MS + 2 * l.S * CX_TWB + l.S * 6 * 16 * CX_TWB + 4 * 32 * CX_TP) * 4;
         l.nblk_E = l.use_cx ? l.nblk_cx : l.nblk_elbo;
+        int64_t nb = (l.own_cnt + NT - 1) / NT;
+        l.nblk_psum = (int)(nb < 512 ? nb : 512);
     }
     // ---- matrix-core equaliser path: complex, second-order lags odd <= 31, centred first-order window inside it
     l.use_eqcx = (l.mode == 1 && l.l2 >= 1 && l.l2 <= 31 && (l.l1 & 1) && l.l1 <= l.l2 && l.pad1 == l.l1 / 2 &&
@@ -157,6 +165,8 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     l.o_cxh1 = take((int64_t)l.S * 2 * 16);
     l.o_part_cx = take(l.use_cx ? (int64_t)l.nblk_cx * l.S * CX_REC : 0);
     l.o_tot_cx = take((int64_t)l.S * CX_REC);
+    l.o_psum_part = take(2 * 16 * (int64_t)l.nblk_psum);
+    l.o_psum_tot = take(2 * 16);
     l.o_eqcxA = take(l.use_eqcx ? (int64_t)2 * l.eqcx_steps * 64 : 0);
     l.o_part_eqcx = take(l.use_eqcx ? (int64_t)l.nblk_eq * 4096 : 0);
     l.o_tot_eqcx = take(l.use_eqcx ? 4096 : 0);
@@ -1193,6 +1203,13 @@ size_t v2vae_workspace_bytes(const v2vae_problem* p) {
     if (make_layout(p, &l) != V2VAE_OK) return 0;
     return (size_t)l.total_floats * sizeof(float);
 }
+
+#ifdef V2VAE_STAMPS
+int64_t v2vae_dbg_offset(const v2vae_problem* p) {
+    Lay l;
+    return make_layout(p, &l) == V2VAE_OK ? l.o_sumstage : -1;
+}
+#endif
 
 int64_t v2vae_ws_offset_moments(const v2vae_problem* p) {
     Lay l;

@@ -46,7 +46,8 @@ struct Lay {
     int lds_eq;              // bytes (forward and backward use the same carve)
     int nblk_sym;
     // matrix-core ELBO path
-    int use_cx, ntile_cx, nblk_cx, lds_cx, nblk_E;
+    int use_cx, cx_gen, cx_waves, ntile_cx, nblk_cx, lds_cx, nblk_E, nblk_psum;
+    int64_t o_psum_part, o_psum_tot;
     int64_t o_cxH, o_cxh1, o_part_cx, o_tot_cx;
     // matrix-core equaliser path
     int use_eqcx, eqcx_lk, eqcx_steps;
