@@ -25,13 +25,19 @@ PEAK_FP32_TFLOPS = 157.3  # MI355X dense fp32 (vector == f32 MFMA) peak
 
 
 def algorithmic_flops_per_symbol(L, S, l1, l2, cplx):
-    """Per-symbol algorithmic flops of each compute kernel and of the whole step (real arithmetic;
-    complex arithmetic counts 4 real multiply-adds per complex one)."""
+    """Per-symbol algorithmic flops (2 per multiply-add) of each compute kernel.
+
+    Equaliser (real): forward 2 l1 + 2 l2^2 + 2 l2, backward 2 l1 + 2 l2^2; complex arithmetic costs 4 real
+    multiply-adds per complex one.  ELBO per window on Le = L / S active taps, S windows per symbol:
+      real     H mu, (H.H) v, H w (3 mat-vecs) + 3 rank-1 accumulations           = 12 Le^2 flops
+      complex  H X and H w (complex mat-vecs, 8 Le^2 each), one complex rank-1 accumulation (8 Le^2),
+               (|H|^2) s (2 Le^2); the s s^T accumulation is O(Le) (lagged products)  = 26 Le^2 flops
+    i.e. only work the kernels actually execute is counted (the stacked real-valued formulation would be 48 Le^2)."""
     c = 4 if cplx else 1
     return {
         "eq_fwd": c * (2 * l1 + 2 * l2 * l2 + 2 * l2),
         "eq_bwd": c * (2 * l1 + 2 * l2 * l2),
-        "elbo_fused": c * 12 * L * L / S,
+        "elbo_fused": (26 if cplx else 12) * L * L / S,
     }
 
 

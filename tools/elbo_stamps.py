@@ -2,7 +2,7 @@ import os, sys, ctypes, numpy as np, torch
 sys.path.insert(0, os.getcwd())
 import volterra_vae_amd._lib as L
 # swap in the instrumented library
-lib = ctypes.CDLL(os.path.join(os.getcwd(), "tools/libv2vae_stamps.so"))
+lib = ctypes.CDLL(os.path.join(os.getcwd(), ""+os.environ.get("STAMPLIB","tools/libstamps_NONE.so")+""))
 for name, (res, args) in L.EXPORTS.items():
     fn = getattr(lib, name); fn.restype = res; fn.argtypes = args
 L.lib = lib

@@ -340,19 +340,23 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
     // one staging buffer: moments as float4 (mean, variance, 3rd central moment, 4th cumulant) [2][MS], the means
     // again as plain arrays [2][MS] (MFMA operands want unit stride), s = v_a + v_b [MS], y' [2][S][TWB]
     constexpr int STG = 11 * MS + 2 * S * TWB;
-    float* s_stage = sm;                      // [2][STG] double buffered
-    float* s_A = s_stage + 2 * STG;           // [S][40][64]  A operands: steps 0-15 H X, 16-23 (H.H) s, 24-39 H w
+    float* s_stage = sm;                      // [STG]; the next tile travels in registers until this one is consumed
+    float* s_A = s_stage + STG;           // [S][40][64]  A operands: steps 0-15 H X, 16-23 (H.H) s, 24-39 H w
     float* s_c = s_A + S * 40 * 64;           // [S][4][16]   h1r, h1i, diag Hr, diag Hi
     float* s_T = s_c + S * 64;                // [8 waves][32 * TP]  transposing buffer of rho / sigma
-    float* s_B = s_T + NW * 32 * TP;           // [NW waves][16][64] anti-diagonal buffer: columns 16..47 live, the rest stays 0
-    float* s_P = s_B + NW * 1024;              // [S][NU][6][NSIG]
+    // anti-diagonal buffers, two per wave: 16 leading zeros, then 16 rows of 32 live + 16 zero entries (pitch 48), so
+    // that window index -15..47 of any row reads either data or zeros
+    constexpr int ADB = 16 + 16 * 48;
+    float* s_B = s_T + NW * 32 * TP;           // [NW waves][2][ADB]
+    float* s_P = s_B + NW * 2 * ADB;           // [S][NU][6][NSIG]
     __shared__ double dred[CX2_NT / 64];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int r = wv / NWP, wsub = wv % NWP;
     float* Tb = s_T + wv * 32 * TP;
-    float* Bd = s_B + wv * 1024;
+    float* Bd0 = s_B + wv * 2 * ADB + 16;
+    float* Bd1 = Bd0 + ADB;
     const float* __restrict__ mom = ws + l.o_mom;
     float* __restrict__ gmom = ws + l.o_gmom;
     const int64_t own_hi = l.own_lo + l.own_cnt, sym_hi = l.sym_lo + l.sym_cnt;
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
         s_c[idx] = q == 0 ? ws[l.o_cxh1 + (rr * 2 + 0) * 16 + x] : q == 1 ? ws[l.o_cxh1 + (rr * 2 + 1) * 16 + x]
                  : q == 2 ? Hr[x * 16 + x] : Hi[x * 16 + x];
     }
-    for (int idx = tid; idx < NW * 1024; idx += CX2_NT) s_B[idx] = 0.f;
+    for (int idx = tid; idx < NW * 2 * ADB; idx += CX2_NT) s_B[idx] = 0.f;
     const float* Aop = s_A + (size_t)r * 40 * 64 + lane;
     // per-tap constants stay in LDS (all lanes of a half read one address: a broadcast, no bank conflict)
     const float* cst = s_c + r * 64 + 4 * h;
@@ -486,7 +490,6 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
             if (e < 2 * S * TWB) dst[11 * MS + e] = prey[u];
         }
     };
-    int buf = 0;
     if (blockIdx.x < l.ntile_cx) { stage_load(blockIdx.x); stage_store(s_stage); }
     __syncthreads();
 
@@ -494,8 +497,8 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
         const int64_t s0 = l.own_lo + (int64_t)tile * TS;
         const int64_t s1 = (s0 + TS < own_hi) ? s0 + TS : own_hi;
         const int64_t tbase = s0 - l.kmax;
-        const float4* s_m4 = reinterpret_cast<const float4*>(s_stage + buf * STG);   // [2][MS]
-        const float* s_mu = s_stage + buf * STG + 8 * MS;                             // [2][MS]
+        const float4* s_m4 = reinterpret_cast<const float4*>(s_stage);   // [2][MS]
+        const float* s_mu = s_stage + 8 * MS;                             // [2][MS]
         const float* s_S = s_mu + 2 * MS;
         const float* s_yw = s_S + MS;
         const bool more = tile + (int)gridDim.x < l.ntile_cx;
@@ -516,7 +519,11 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
             for (int s = 0; s < 16; ++s) {
                 const int k = 2 * s + h;
                 const float b = s_mu[(k >> 4) * MS + tsl + i + (k & 15)];
+#ifdef ABLATE_U
+                U[s] += Aop[s * 64] * b;
+#else
                 U = MFMA32(Aop[s * 64], b, U);
+#endif
             }
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
@@ -567,8 +574,13 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
             f32x16 HW;
 #pragma unroll
             for (int g = 0; g < 16; ++g) HW[g] = 0.f;
+#ifdef ABLATE_HW
+#pragma unroll
+            for (int s = 0; s < 16; ++s) HW[s] = (s < 8 ? al[s & 7] : be[s & 7]);
+#else
 #pragma unroll
             for (int s = 0; s < 16; ++s) HW = MFMA32(Aop[(24 + s) * 64], s < 8 ? al[s & 7] : be[s & 7], HW);
+#endif
 
             // ---- anti-diagonal sums of the moment gradients, two quantities per round through the wave's buffer
             STAMP(3);
@@ -576,30 +588,45 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
             //      the wave's zero-padded buffer.  LDS instructions of one wave execute in program order, so lanes may
             //      read what other lanes of the same wave wrote earlier; wave_barrier only pins the compiler's ordering.
             float* Pu = s_P + ((size_t)(r * NU + sub) * 6) * NSIG;
+#ifdef ABLATE_ANTIDIAG
 #pragma unroll
-            for (int round = 0; round < 6; ++round) {
+            for (int q = 0; q < 8; ++q) asm volatile("" ::"v"(HW[q]), "v"(HW[q + 8]), "v"(zz[q]));
+#else
+#pragma unroll
+            for (int round = 0; round < 3; ++round) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int x = cx_kk(q, h);
                     const float zp = zP[q], zq = zQ[q], dr = C_DR(q), di = C_DI(q);
-                    float d;
-                    if (round == 0) d = 2.f * (e0 * zp + e1 * zq) + 2.f * HW[q];
-                    else if (round == 1) d = 2.f * (e1 * zp - e0 * zq) + 2.f * HW[q + 8];
-                    else if (round == 2) d = zz[q] + 2.f * (e0 * dr + e1 * di);
-                    else if (round == 3) d = zz[q] - 2.f * (e0 * dr + e1 * di);
-                    else if (round == 4) d = 2.f * (dr * zp + di * zq);
-                    else d = 2.f * (dr * zq - di * zp);
-                    Bd[x * 64 + 16 + i] = mv * d;
+                    float da, db;
+                    if (round == 0) {
+                        da = 2.f * (e0 * zp + e1 * zq) + 2.f * HW[q];
+                        db = 2.f * (e1 * zp - e0 * zq) + 2.f * HW[q + 8];
+                    } else if (round == 1) {
+                        const float ed = 2.f * (e0 * dr + e1 * di);
+                        da = zz[q] + ed;
+                        db = zz[q] - ed;
+                    } else {
+                        da = 2.f * (dr * zp + di * zq);
+                        db = 2.f * (dr * zq - di * zp);
+                    }
+                    Bd0[x * 48 + i] = mv * da;
+                    Bd1[x * 48 + i] = mv * db;
                 }
                 __builtin_amdgcn_wave_barrier();
                 if (lane < 48) {
-                    float sa = 0.f;
+                    float sa = 0.f, sb = 0.f;
 #pragma unroll
-                    for (int x = 0; x < 16; ++x) sa += Bd[x * 63 + 16 + lane];   // row x, column 16 + (lane - x)
-                    Pu[round * NSIG + lane] = sa;
+                    for (int x = 0; x < 16; ++x) {   // row x, window lane - x
+                        sa += Bd0[x * 47 + lane];
+                        sb += Bd1[x * 47 + lane];
+                    }
+                    Pu[(2 * round + 0) * NSIG + lane] = sa;
+                    Pu[(2 * round + 1) * NSIG + lane] = sb;
                 }
                 __builtin_amdgcn_wave_barrier();
             }
+#endif
 
             STAMP(4);
             // ---- rho / sigma (transposed through LDS), vector gradients
@@ -622,14 +649,17 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
                 const int w = 2 * s + h;
                 const float a = Tb[w * TP + i];
                 const float b = s_mu[cj * MS + tsl + w + yj];
+#ifdef ABLATE_G
+                R[s] += a * b;
+#else
                 R = MFMA32(a, b, R);
+#endif
             }
             __builtin_amdgcn_wave_barrier();
             STAMP(5);
         }
-        if (more) stage_store(s_stage + (buf ^ 1) * STG);
-        buf ^= 1;
         __syncthreads();
+        if (more) stage_store(s_stage);
         // ---- gather: symbol slot ms = kmax + ml is covered by subtile ms / 32 and, if ms % 32 <= Le - 2, by the one before
         for (int idx = tid; idx < 2 * TS; idx += CX2_NT) {
             const int c = idx / TS, ml = idx - c * TS;

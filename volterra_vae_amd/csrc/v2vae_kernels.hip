@@ -128,7 +128,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
         l.ntile_cx = (int)((l.own_cnt + ts - 1) / ts);
         l.nblk_cx = l.ntile_cx < CX_BLOCKS ? l.ntile_cx : CX_BLOCKS;
         if (l.cx_gen == 2)
-            l.lds_cx = (2 * (11 * (256 + 48) + 2 * l.S * 256) + l.S * 40 * 64 + l.S * 64 + 8 * 32 * CX_TP + 8 * 1024 + l.S * 8 * 6 * 64) * 4;
+            l.lds_cx = ((11 * (256 + 48) + 2 * l.S * 256) + l.S * 40 * 64 + l.S * 64 + 8 * 32 * CX_TP + 8 * 2 * (16 + 16 * 48) + l.S * 8 * 6 * 64) * 4;
         else
             l.lds_cx = (8 * CX_MS + CX_MS + 2 * l.S * CX_TWB + l.S * 6 * 16 * CX_TWB + 4 * 32 * CX_TP) * 4;
         l.nblk_E = l.use_cx ? l.nblk_cx : l.nblk_elbo;
@@ -374,6 +374,7 @@ struct Posterior {
     float mu, var, kap, gam;
 };
 
+template <int CB>
 __device__ __forceinline__ void posterior(float x, const float* __restrict__ lv, const float* __restrict__ sc, int C,
                                           float nv, Posterior& p) {
     // Logits reach |z| ~ 1e2..1e3 for small noise variance; rounding them to fp32 before the max is
@@ -382,7 +383,7 @@ __device__ __forceinline__ void posterior(float x, const float* __restrict__ lv,
     double zd[MAX_C];
     double mx = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < MAX_C; ++i)
+    for (int i = 0; i < CB; ++i)
         if (i < C) {
             const double d = (double)x - (double)lv[i];
             zd[i] = -(d * d) / ((double)nv * (double)sc[i]);
@@ -390,7 +391,7 @@ __device__ __forceinline__ void posterior(float x, const float* __restrict__ lv,
         }
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAX_C; ++i)
+    for (int i = 0; i < CB; ++i)
         if (i < C) {
             p.q[i] = expf((float)(zd[i] - mx));
             sum += p.q[i];
@@ -398,14 +399,14 @@ __device__ __forceinline__ void posterior(float x, const float* __restrict__ lv,
     const float inv = 1.f / sum;
     float mu = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAX_C; ++i)
+    for (int i = 0; i < CB; ++i)
         if (i < C) {
             p.q[i] *= inv;
             mu = fmaf(p.q[i], lv[i], mu);
         }
     float v = 0.f, k3 = 0.f, c4 = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAX_C; ++i)
+    for (int i = 0; i < CB; ++i)
         if (i < C) {
             const float d = lv[i] - mu, d2 = d * d;
             v = fmaf(p.q[i], d2, v);
@@ -415,6 +416,7 @@ __device__ __forceinline__ void posterior(float x, const float* __restrict__ lv,
     p.mu = mu; p.var = v; p.kap = k3; p.gam = c4 - 3.f * v * v;
 }
 
+template <int CB>
 __global__ __launch_bounds__(NT) void k_demap_moments(Lay l, const float* __restrict__ xhat, const float* __restrict__ levels,
                                                       const float* __restrict__ prior, const float* __restrict__ scaling,
                                                       const float* __restrict__ noise_var, float* __restrict__ ws,
@@ -428,12 +430,12 @@ __global__ __launch_bounds__(NT) void k_demap_moments(Lay l, const float* __rest
         const bool in_kl = b >= l.kl_lo && b < l.kl_hi && b >= l.own_lo && b < l.own_lo + l.own_cnt;
         for (int c = 0; c < l.ns; ++c) {
             Posterior p;
-            posterior(xhat[(int64_t)c * l.sym_cnt + i], levels + c * l.C, scaling + c * l.C, l.C, nv, p);
+            posterior<CB>(xhat[(int64_t)c * l.sym_cnt + i], levels + c * l.C, scaling + c * l.C, l.C, nv, p);
             float* m = mom + (int64_t)c * 4 * l.sym_cnt + i;
             m[0] = p.mu; m[l.sym_cnt] = p.var; m[2 * l.sym_cnt] = p.kap; m[3 * l.sym_cnt] = p.gam;
             float klb = 0.f;
 #pragma unroll
-            for (int k = 0; k < MAX_C; ++k)
+            for (int k = 0; k < CB; ++k)
                 if (k < l.C) {
                     if (q_out) q_out[((int64_t)c * l.C + k) * l.sym_cnt + i] = p.q[k];
                     klb += p.q[k] * logf(p.q[k] / prior[c * l.C + k] + 1e-12f);
@@ -466,6 +468,7 @@ __global__ __launch_bounds__(NT) void k_decide(Lay l, const float* __restrict__ 
 // ------------------------------------------------------------------------------------------
 // per-symbol backward
 // ------------------------------------------------------------------------------------------
+template <int CB>
 __global__ __launch_bounds__(NT) void k_sym_bwd(Lay l, const float* __restrict__ xhat, const float* __restrict__ levels,
                                                 const float* __restrict__ prior, const float* __restrict__ scaling,
                                                 const float* __restrict__ noise_var, const double* __restrict__ scal,
@@ -480,7 +483,7 @@ __global__ __launch_bounds__(NT) void k_sym_bwd(Lay l, const float* __restrict__
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int k = 0; k < MAX_C; ++k) gs[c][k] = 0.f;
+        for (int k = 0; k < CB; ++k) gs[c][k] = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < l.sym_cnt; i += (int64_t)gridDim.x * NT) {
         const int64_t b = l.sym_lo + i;
         const bool own = b >= l.own_lo && b < l.own_lo + l.own_cnt;
@@ -494,7 +497,7 @@ __global__ __launch_bounds__(NT) void k_sym_bwd(Lay l, const float* __restrict__
                     const float* lv = levels + c * l.C;
                     const float* sc = scaling + c * l.C;
                     Posterior p;
-                    posterior(x, lv, sc, l.C, nv, p);
+                    posterior<CB>(x, lv, sc, l.C, nv, p);
                     const float* g = gmom + (int64_t)c * 4 * l.sym_cnt + i;
                     const float gmu = g[0], gv = g[l.sym_cnt], gk = g[2 * l.sym_cnt], gg = g[3 * l.sym_cnt];
                     // Softmax backward cancels dq against its posterior mean; for peaked posteriors the
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(NT) void k_sym_bwd(Lay l, const float* __restrict__
                     double dq[MAX_C];
                     double qdq = 0.0;
 #pragma unroll
-                    for (int k = 0; k < MAX_C; ++k)
+                    for (int k = 0; k < CB; ++k)
                         if (k < l.C) {
                             const double d = (double)lv[k] - (double)p.mu, d2 = d * d;
                             double v = (double)gmu * d + (double)gv * d2 + (double)gk * (d2 * d - 3.0 * (double)p.var * d) +
@@ -518,7 +521,7 @@ __global__ __launch_bounds__(NT) void k_sym_bwd(Lay l, const float* __restrict__
                         }
                     double gxd = 0.0;
 #pragma unroll
-                    for (int k = 0; k < MAX_C; ++k)
+                    for (int k = 0; k < CB; ++k)
                         if (k < l.C) {
                             const double dz = (double)p.q[k] * (dq[k] - qdq);
                             const double df = (double)x - (double)lv[k];
@@ -536,7 +539,7 @@ __global__ __launch_bounds__(NT) void k_sym_bwd(Lay l, const float* __restrict__
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int k = 0; k < MAX_C; ++k) {
+        for (int k = 0; k < CB; ++k) {
             float v = gs[c][k];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
             if (lane == 0) red[wv][c * MAX_C + k] = v;
@@ -1255,8 +1258,14 @@ int v2vae_demap_moments(const v2vae_problem* p, const float* xhat, const float* 
     int rc = make_layout(p, &l);
     if (rc) return rc;
     if (!xhat || !levels || !prior || !scaling || !noise_var || !ws) return V2VAE_EINVAL;
-    hipLaunchKernelGGL(k_demap_moments, dim3(l.nblk_sym), dim3(NT), 0, (hipStream_t)stream, l, xhat, levels, prior,
-                       scaling, noise_var, (float*)ws, q_out);
+#define V2VAE_LAUNCH_DEMAP(CB)                                                                                     \
+    hipLaunchKernelGGL(k_demap_moments<CB>, dim3(l.nblk_sym), dim3(NT), 0, (hipStream_t)stream, l, xhat, levels, prior, \
+                       scaling, noise_var, (float*)ws, q_out)
+    if (l.C <= 2) V2VAE_LAUNCH_DEMAP(2);
+    else if (l.C <= 4) V2VAE_LAUNCH_DEMAP(4);
+    else if (l.C <= 8) V2VAE_LAUNCH_DEMAP(8);
+    else V2VAE_LAUNCH_DEMAP(16);
+#undef V2VAE_LAUNCH_DEMAP
     return launch_status();
 }
 
@@ -1318,8 +1327,14 @@ int v2vae_sym_bwd(const v2vae_problem* p, const float* xhat, const float* levels
     int rc = make_layout(p, &l);
     if (rc) return rc;
     if (!xhat || !levels || !prior || !scaling || !noise_var || !scal || !ws || !gxhat) return V2VAE_EINVAL;
-    hipLaunchKernelGGL(k_sym_bwd, dim3(l.nblk_sym), dim3(NT), 0, (hipStream_t)stream, l, xhat, levels, prior, scaling,
-                       noise_var, scal, grad_scale, (float*)ws, gxhat);
+#define V2VAE_LAUNCH_SYMB(CB)                                                                                     \
+    hipLaunchKernelGGL(k_sym_bwd<CB>, dim3(l.nblk_sym), dim3(NT), 0, (hipStream_t)stream, l, xhat, levels, prior,     \
+                       scaling, noise_var, scal, grad_scale, (float*)ws, gxhat)
+    if (l.C <= 2) V2VAE_LAUNCH_SYMB(2);
+    else if (l.C <= 4) V2VAE_LAUNCH_SYMB(4);
+    else if (l.C <= 8) V2VAE_LAUNCH_SYMB(8);
+    else V2VAE_LAUNCH_SYMB(16);
+#undef V2VAE_LAUNCH_SYMB
     return launch_status();
 }
 
