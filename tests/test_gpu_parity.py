@@ -139,3 +139,28 @@ def test_complex_step_matches_oracle(L, S, l1, l2, B, M):
     assert rel(out["g"]["sc"], tsc.grad) < TOL
     if k2 is not None:
         assert rel(out["g"]["k2"], tk2.grad) < TOL
+
+
+def test_complex_L65_shape_runs_on_generic_kernels():
+    """64-QAM, channel memory 65, 65 lags (the shape of the 8-GPU configuration) at a size the CPU oracle handles."""
+    from oracle import v2vae_oracle as orc
+    from volterra_vae_amd.ops import Plan
+    L, S, l1, l2, B, M = 65, 2, 65, 65, 900, 8
+    y, levels, prior, scaling, h1, h2, k1, k2 = _complex_inputs(6, L, S, l1, l2, B, M)
+    h2 *= 0.3
+    k2 *= 0.3
+    nv = 0.1
+    t = lambda a: torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    th1, th2, tk1, tk2, tsc = t(h1), t(h2), t(k1), t(k2), t(scaling)
+    ty = torch.tensor(y)
+    xr = orc.complex_equaliser(ty, tk1[0], tk1[1], tk2[0], tk2[1], S)
+    loss, E, kl = orc.complex_v2vae_loss(xr, ty, th1[0], th1[1], th2[0], th2[1], torch.tensor(levels), torch.tensor(prior),
+                                         torch.tensor(nv, dtype=torch.float64), tsc, S)
+    loss.backward()
+    plan = Plan(ns=2, sps=S, l1=l1, pad1=l1 // 2, l2=l2, L=L, C_levels=M, n_glob=B * S, device="cuda")
+    out = run_step(plan, dev(y), dev(h1), dev(h2), dev(k1), dev(k2), dev(levels), dev(prior), dev(scaling), dev(np.array([nv])))
+    assert rel(out["xhat"], xr.detach().numpy()) < TOL
+    assert abs(out["loss"] - float(loss.detach())) < TOL * abs(float(loss.detach()))
+    for ours, ref in ((out["g"]["h1"], th1.grad), (out["g"]["h2"], th2.grad), (out["g"]["k1"], tk1.grad),
+                      (out["g"]["k2"], tk2.grad), (out["g"]["sc"], tsc.grad)):
+        assert rel(ours, ref) < TOL

@@ -869,8 +869,6 @@ int launch_elbo_cx(const Lay& l, const float* y, float* ws, hipStream_t st) {
     const int lds = l.lds_cx;
     hipError_t e = hipSuccess;
     if (l.cx_gen == 2) {
-        hipLaunchKernelGGL(k_psum_cx, dim3(l.nblk_psum), dim3(NT), 0, st, l, ws);
-        hipLaunchKernelGGL(k_psum_finish_cx, dim3(1), dim3(NT), 0, st, l, ws);
 #define V2VAE_LAUNCH_CX2(SS, NWV)                                                                                          \
     do {                                                                                                                   \
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_elbo_cx2<SS, NWV>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
@@ -892,6 +890,12 @@ int launch_elbo_cx(const Lay& l, const float* y, float* ws, hipStream_t st) {
         hipLaunchKernelGGL(k_elbo_cx<2>, dim3(l.nblk_cx), dim3(NT), lds, st, l, y, ws);
     }
     return V2VAE_OK;
+}
+
+// lagged products of s = v_a + v_b (needs only the moments, so it runs right after the soft demapper)
+void launch_psum_cx(const Lay& l, float* ws, hipStream_t st) {
+    hipLaunchKernelGGL(k_psum_cx, dim3(l.nblk_psum), dim3(NT), 0, st, l, ws);
+    hipLaunchKernelGGL(k_psum_finish_cx, dim3(1), dim3(NT), 0, st, l, ws);
 }
 
 void launch_finish_channel_cx(const Lay& l, float* ws, const double* scal, const float* grad_scale, float* g_h1, float* g_h2,

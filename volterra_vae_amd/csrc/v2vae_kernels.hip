@@ -1266,6 +1266,7 @@ int v2vae_demap_moments(const v2vae_problem* p, const float* xhat, const float* 
     else if (l.C <= 8) V2VAE_LAUNCH_DEMAP(8);
     else V2VAE_LAUNCH_DEMAP(16);
 #undef V2VAE_LAUNCH_DEMAP
+    if (l.use_cx && l.cx_gen == 2) launch_psum_cx(l, (float*)ws, (hipStream_t)stream);
     return launch_status();
 }
 

@@ -69,6 +69,7 @@ int make_layout(const v2vae_problem* p, Lay* out);
 
 // v2vae_elbo_cx.hip
 int launch_elbo_cx(const Lay& l, const float* y, float* ws, hipStream_t st);
+void launch_psum_cx(const Lay& l, float* ws, hipStream_t st);
 void launch_finish_channel_cx(const Lay& l, float* ws, const double* scal, const float* grad_scale, float* g_h1, float* g_h2,
                               hipStream_t st);
 
