@@ -179,6 +179,14 @@ def main():
         achieved = fl[dom] * sr.own_cnt / (kernel_ms[dom] * 1e-3) / 1e12
         step_flops = sum(fl.values()) * b_glob
         ms_per_step = elapsed / args.steps * 1e3
+        traffic = None
+        try:  # HBM bytes per launch of the dominant kernel, measured with rocprofv3 --pmc passes (committed under profiles/)
+            with open(os.path.join(ROOT, "profiles", "latest_traffic.json")) as fh:
+                tr = json.load(fh)
+            if dom == "elbo_fused" and world == 1 and args.log2_symbols == 22:
+                traffic = next(v for k, v in tr.items() if "k_elbo_cx2" in k)
+        except Exception:
+            traffic = None
         out = {
             "metric": "V2VAE train-step symbols/sec (fwd+bwd) at 1/2/4/8 MI355X; % of HBM/MFMA roofline",
             "value": b_glob * args.steps / elapsed, "unit": "symbols/s", "n_gpus": world, "steps": args.steps,
@@ -188,7 +196,7 @@ def main():
                                    "Adam-AMSGrad, random-init (dirac) kernels, synthetic Wiener-Hammerstein ISI at 16 dB",
                        "symbols_per_gpu": b_per_gpu, "parallelism": f"halo-sharded dp{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
                          "algorithmic_flops_per_symbol": fl[dom], "kernel_ms": kernel_ms[dom],
                          "whole_step_frac": step_flops / world / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_TFLOPS},
             "kernel_ms": kernel_ms, "final_loss": final_loss,
