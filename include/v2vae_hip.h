@@ -158,6 +158,49 @@ typedef struct v2vae_train_args {
  * on `stream` with no host synchronisation. */
 int v2vae_train_step(const v2vae_problem* p, const v2vae_train_args* a, void* stream);
 
+typedef struct v2vae_fit_args {
+    const float* y;           /* model m, stream c, sample i of batch n: y[m*y_model_stride + c*y_stream_stride + n*B*sps + i] */
+    int64_t y_model_stride;   /* 0: every model trains on the same sequence */
+    int64_t y_stream_stride;  /* >= n_batches * B * sps */
+    const float* levels;      /* [ns][C], shared by all models */
+    const float* prior;       /* [ns][C], shared */
+    float* params;            /* [n_models][pack], pack = sum of v2vae_pack_sizes */
+    float* grads;             /* [n_models][pack] scratch (holds the last batch's gradients on return) */
+    float* adam_m;            /* [n_models][pack] each */
+    float* adam_v;
+    float* adam_vmax;
+    float* noise_var;         /* [n_models] */
+    void* ws;                 /* n_models * v2vae_workspace_bytes(p), zero-initialised once */
+    double* scal;             /* [n_models][V2VAE_SCAL_COUNT] */
+    float* xhat;              /* [n_models][ns][B] scratch */
+    float* gxhat;             /* [n_models][ns][B] scratch */
+    float* y_eq;              /* [n_models][ns][n_batches*B] equaliser output of every batch, before its update; may be NULL */
+    float* loss_curve;        /* [n_models][n_batches]; may be NULL */
+    const float* step_size;   /* [n_batches] device array from v2vae_adam_schedule */
+    const float* bc2_sqrt;    /* [n_batches] device array from v2vae_adam_schedule */
+    float beta1, beta2, eps;
+    int32_t n_models;
+    int32_t n_batches;
+    int32_t learn_scaling;
+    int32_t adaptive_noise;
+} v2vae_fit_args;
+
+/* Host-side helper (no GPU work): per-step Adam constants of v2vae_adam_amsgrad for steps
+ * step0+1 .. step0+n with learning rates lr[0..n) (the StepLR schedule of
+ * lib/real_equalization.py:476-480,499 evaluated by the caller): step_size[i] = lr[i] / (1 - beta1^step),
+ * bc2_sqrt[i] = sqrt(1 - beta2^step).  Both outputs are HOST arrays the caller copies to the device. */
+int v2vae_adam_schedule(int64_t step0, int64_t n, const float* lr, float beta1, float beta2, float* step_size,
+                        float* bc2_sqrt);
+
+/* The whole mini-batch loop of GenericTorchBlindEqualizer.fit (lib/real_equalization.py:482-502) for n_models
+ * independent models in ONE launch: one workgroup per model runs n_batches sequential training steps
+ * (same stages, same arithmetic and summation order as v2vae_train_step on the generic kernels), so the
+ * launch-bound small-batch configuration costs one launch per fit instead of ~17 per batch, and a sweep of
+ * models (channels / SNR points / seeds) fills the GPU.  `p` describes ONE batch as a whole sequence
+ * (n_glob = y_len = B*sps, y_lo = sym_lo = own_lo = 0, sym_cnt = own_cnt = B).  V2VAE_ESIZE if the shape
+ * needs more than one accumulator tile per thread in the ELBO stage (then use v2vae_train_step). */
+int v2vae_fit_persistent(const v2vae_problem* p, const v2vae_fit_args* a, void* stream);
+
 /* Read-only views into the workspace for tests and tooling: float offsets (in floats from the
  * workspace base) of the per-symbol moments [ns][4][sym_cnt] and of dE/d(moments), same shape. */
 int64_t v2vae_ws_offset_moments(const v2vae_problem* p);

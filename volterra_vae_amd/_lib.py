@@ -42,6 +42,17 @@ class TrainArgs(C.Structure):
                 ("step", C.c_int64), ("learn_scaling", C.c_int32), ("adaptive_noise", C.c_int32)]
 
 
+class FitArgs(C.Structure):
+    _fields_ = [("y", C.c_void_p), ("y_model_stride", C.c_int64), ("y_stream_stride", C.c_int64),
+                ("levels", C.c_void_p), ("prior", C.c_void_p), ("params", C.c_void_p), ("grads", C.c_void_p),
+                ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("adam_vmax", C.c_void_p), ("noise_var", C.c_void_p),
+                ("ws", C.c_void_p), ("scal", C.c_void_p), ("xhat", C.c_void_p), ("gxhat", C.c_void_p),
+                ("y_eq", C.c_void_p), ("loss_curve", C.c_void_p), ("step_size", C.c_void_p), ("bc2_sqrt", C.c_void_p),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("n_models", C.c_int32), ("n_batches", C.c_int32), ("learn_scaling", C.c_int32),
+                ("adaptive_noise", C.c_int32)]
+
+
 EXPORTS = {
     # name: (restype, argtypes)
     "v2vae_version": (C.c_char_p, []),
@@ -61,6 +72,8 @@ EXPORTS = {
     "v2vae_decide": (C.c_int, [C.POINTER(Problem)] + [C.c_void_p] * 6),
     "v2vae_pack_sizes": (None, [C.POINTER(Problem), C.POINTER(C.c_int64 * 5)]),
     "v2vae_train_step": (C.c_int, [C.POINTER(Problem), C.POINTER(TrainArgs), C.c_void_p]),
+    "v2vae_adam_schedule": (C.c_int, [C.c_int64, C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    "v2vae_fit_persistent": (C.c_int, [C.POINTER(Problem), C.POINTER(FitArgs), C.c_void_p]),
     "v2vae_ws_offset_moments": (C.c_int64, [C.POINTER(Problem)]),
     "v2vae_ws_offset_gmoments": (C.c_int64, [C.POINTER(Problem)]),
 }

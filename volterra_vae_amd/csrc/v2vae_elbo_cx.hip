@@ -117,7 +117,7 @@ __global__ __launch_bounds__(NT) void k_elbo_cx(Lay l, const float* __restrict__
             float v = 0.f;
             if (t < s1 && n >= 0 && n < l.W) {
                 const int64_t loc = l.pre + n - l.y_lo;
-                if (loc >= 0 && loc < l.y_len) v = y[(int64_t)o * l.y_len + loc];
+                if (loc >= 0 && loc < l.y_len) v = y[(int64_t)o * l.y_stride + loc];
             }
             s_yw[idx] = v;
         }
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
             float v = 0.f;
             if (e < 2 * S * TWB && t < s1 && n >= 0 && n < l.W) {
                 const int64_t loc = l.pre + n - l.y_lo;
-                if (loc >= 0 && loc < l.y_len) v = y[(int64_t)o * l.y_len + loc];
+                if (loc >= 0 && loc < l.y_len) v = y[(int64_t)o * l.y_stride + loc];
             }
             prey[u] = v;
         }

@@ -30,7 +30,7 @@ __device__ __forceinline__ void eqcx_load_tile(const Lay& l, const float* __rest
         float v = 0.f;
         if (g >= 0 && g < l.n_glob) {
             const int64_t loc = g - l.y_lo;
-            if (loc >= 0 && loc < l.y_len) v = y[(int64_t)c * l.y_len + loc];
+            if (loc >= 0 && loc < l.y_len) v = y[(int64_t)c * l.y_stride + loc];
         }
         tile[idx] = v;
     }

@@ -25,6 +25,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     l.L = p->L; l.C = p->C;
     l.n_glob = p->n_glob; l.y_lo = p->y_lo; l.y_len = p->y_len; l.sym_lo = p->sym_lo;
     l.sym_cnt = p->sym_cnt; l.own_lo = p->own_lo; l.own_cnt = p->own_cnt;
+    l.y_stride = l.y_len;
     if (l.ns < 1 || l.ns > 2) return V2VAE_EINVAL;
     if ((l.mode == 0) != (l.ns == 1)) return V2VAE_EINVAL;
     if (l.S < 1 || l.S > 8) return V2VAE_EINVAL;
@@ -188,6 +189,13 @@ int make_layout(const v2vae_problem* p, Lay* out) {
 // ------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------
+// Every stage is written as a device function of (block id, block count) so that the same code runs either as
+// its own launch (one call per stage, many workgroups) or back to back inside the persistent fit kernel
+// (one workgroup per model, bid = 0, nb = 1).
+struct GridCtx {
+    int bid, nb;
+};
+
 __device__ __forceinline__ float stacked_quad(int mode, const float* __restrict__ h2, int L, int o, int a, int b) {
     // effective symmetric second-order kernel of output o on the real-stacked tap vector
     if (mode == 0) return h2[a * L + b] + h2[b * L + a];
@@ -239,10 +247,10 @@ __device__ __forceinline__ double block_sum_double(double v, double* red /* >= N
 // ------------------------------------------------------------------------------------------
 // tables
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_prep_tables(Lay l, const float* __restrict__ h1, const float* __restrict__ h2,
+__device__ __forceinline__ void d_prep_tables(const GridCtx gc, Lay l, const float* __restrict__ h1, const float* __restrict__ h2,
                                                     const float* __restrict__ k1, const float* __restrict__ k2,
                                                     float* __restrict__ ws) {
-    const int tid = blockIdx.x * NT + threadIdx.x, nth = gridDim.x * NT;
+    const int tid = gc.bid * NT + threadIdx.x, nth = gc.nb * NT;
     for (int idx = tid; k1 && idx < l.nk1; idx += nth) {
         const int o = idx / (l.ns * l.l1), rem = idx - o * l.ns * l.l1;
         ws[l.o_eqK1 + idx] = stacked_lin(l.mode, k1, l.l1, o, rem);
@@ -294,6 +302,12 @@ __global__ __launch_bounds__(NT) void k_prep_tables(Lay l, const float* __restri
     }
 }
 
+__global__ __launch_bounds__(NT) void k_prep_tables(Lay l, const float* __restrict__ h1, const float* __restrict__ h2,
+                                                    const float* __restrict__ k1, const float* __restrict__ k2,
+                                                    float* __restrict__ ws) {
+    d_prep_tables(GridCtx{(int)blockIdx.x, (int)gridDim.x}, l, h1, h2, k1, k2, ws);
+}
+
 // ------------------------------------------------------------------------------------------
 // equaliser forward
 // ------------------------------------------------------------------------------------------
@@ -306,17 +320,18 @@ __device__ __forceinline__ void load_sample_tile(const Lay& l, const float* __re
         float v = 0.f;
         if (g >= 0 && g < l.n_glob) {
             const int64_t loc = g - l.y_lo;
-            if (loc >= 0 && loc < l.y_len) v = y[(int64_t)c * l.y_len + loc];
+            if (loc >= 0 && loc < l.y_len) v = y[(int64_t)c * l.y_stride + loc];
         }
         tile[idx] = v;
     }
 }
 
-__global__ __launch_bounds__(NT) void k_eq_fwd(Lay l, const float* __restrict__ y, const float* __restrict__ ws,
-                                               float* __restrict__ xhat) {
+// one tile of EQ_TB symbols per block id
+__device__ __forceinline__ void d_eq_fwd(const GridCtx gc, Lay l, const float* __restrict__ y, const float* __restrict__ ws,
+                                         float* __restrict__ xhat) {
     extern __shared__ float sm[];
     float* tile = sm;
-    const int64_t b0 = l.sym_lo + (int64_t)blockIdx.x * EQ_TB;
+    const int64_t b0 = l.sym_lo + (int64_t)gc.bid * EQ_TB;
     load_sample_tile(l, y, b0 * l.S - l.hl, tile);
     __syncthreads();
     const int64_t b = b0 + threadIdx.x;
@@ -364,6 +379,11 @@ __global__ __launch_bounds__(NT) void k_eq_fwd(Lay l, const float* __restrict__ 
         }
     }
     for (int o = 0; o < l.ns; ++o) xhat[(int64_t)o * l.sym_cnt + (b - l.sym_lo)] = out[o];
+}
+
+__global__ __launch_bounds__(NT) void k_eq_fwd(Lay l, const float* __restrict__ y, const float* __restrict__ ws,
+                                               float* __restrict__ xhat) {
+    d_eq_fwd(GridCtx{(int)blockIdx.x, (int)gridDim.x}, l, y, ws, xhat);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -417,7 +437,7 @@ __device__ __forceinline__ void posterior(float x, const float* __restrict__ lv,
 }
 
 template <int CB>
-__global__ __launch_bounds__(NT) void k_demap_moments(Lay l, const float* __restrict__ xhat, const float* __restrict__ levels,
+__device__ __forceinline__ void d_demap_moments(const GridCtx gc, Lay l, const float* __restrict__ xhat, const float* __restrict__ levels,
                                                       const float* __restrict__ prior, const float* __restrict__ scaling,
                                                       const float* __restrict__ noise_var, float* __restrict__ ws,
                                                       float* __restrict__ q_out) {
@@ -425,7 +445,7 @@ __global__ __launch_bounds__(NT) void k_demap_moments(Lay l, const float* __rest
     const float nv = noise_var[0];
     float* __restrict__ mom = ws + l.o_mom;
     double kl = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < l.sym_cnt; i += (int64_t)gridDim.x * NT) {
+    for (int64_t i = (int64_t)gc.bid * NT + threadIdx.x; i < l.sym_cnt; i += (int64_t)gc.nb * NT) {
         const int64_t b = l.sym_lo + i;
         const bool in_kl = b >= l.kl_lo && b < l.kl_hi && b >= l.own_lo && b < l.own_lo + l.own_cnt;
         for (int c = 0; c < l.ns; ++c) {
@@ -444,7 +464,15 @@ __global__ __launch_bounds__(NT) void k_demap_moments(Lay l, const float* __rest
         }
     }
     const double s = block_sum_double(kl, red);
-    if (threadIdx.x == 0) reinterpret_cast<double*>(ws + l.o_KLpart)[blockIdx.x] = s;
+    if (threadIdx.x == 0) reinterpret_cast<double*>(ws + l.o_KLpart)[gc.bid] = s;
+}
+
+template <int CB>
+__global__ __launch_bounds__(NT) void k_demap_moments(Lay l, const float* __restrict__ xhat, const float* __restrict__ levels,
+                                                      const float* __restrict__ prior, const float* __restrict__ scaling,
+                                                      const float* __restrict__ noise_var, float* __restrict__ ws,
+                                                      float* __restrict__ q_out) {
+    d_demap_moments<CB>(GridCtx{(int)blockIdx.x, (int)gridDim.x}, l, xhat, levels, prior, scaling, noise_var, ws, q_out);
 }
 
 __global__ __launch_bounds__(NT) void k_decide(Lay l, const float* __restrict__ xhat, const float* __restrict__ levels,
@@ -469,7 +497,7 @@ __global__ __launch_bounds__(NT) void k_decide(Lay l, const float* __restrict__ 
 // per-symbol backward
 // ------------------------------------------------------------------------------------------
 template <int CB>
-__global__ __launch_bounds__(NT) void k_sym_bwd(Lay l, const float* __restrict__ xhat, const float* __restrict__ levels,
+__device__ __forceinline__ void d_sym_bwd(const GridCtx gc, Lay l, const float* __restrict__ xhat, const float* __restrict__ levels,
                                                 const float* __restrict__ prior, const float* __restrict__ scaling,
                                                 const float* __restrict__ noise_var, const double* __restrict__ scal,
                                                 const float* __restrict__ grad_scale, float* __restrict__ ws,
@@ -484,7 +512,7 @@ __global__ __launch_bounds__(NT) void k_sym_bwd(Lay l, const float* __restrict__
     for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int k = 0; k < CB; ++k) gs[c][k] = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < l.sym_cnt; i += (int64_t)gridDim.x * NT) {
+    for (int64_t i = (int64_t)gc.bid * NT + threadIdx.x; i < l.sym_cnt; i += (int64_t)gc.nb * NT) {
         const int64_t b = l.sym_lo + i;
         const bool own = b >= l.own_lo && b < l.own_lo + l.own_cnt;
         const bool in_kl = own && b >= l.kl_lo && b < l.kl_hi;
@@ -549,15 +577,24 @@ __global__ __launch_bounds__(NT) void k_sym_bwd(Lay l, const float* __restrict__
         const int c = threadIdx.x / l.C, k = threadIdx.x - c * l.C;
         float s = 0.f;
         for (int w = 0; w < NT / 64; ++w) s += red[w][c * MAX_C + k];
-        ws[l.o_part_sym + (int64_t)blockIdx.x * l.rec_sym + threadIdx.x] = s;
+        ws[l.o_part_sym + (int64_t)gc.bid * l.rec_sym + threadIdx.x] = s;
     }
+}
+
+template <int CB>
+__global__ __launch_bounds__(NT) void k_sym_bwd(Lay l, const float* __restrict__ xhat, const float* __restrict__ levels,
+                                                const float* __restrict__ prior, const float* __restrict__ scaling,
+                                                const float* __restrict__ noise_var, const double* __restrict__ scal,
+                                                const float* __restrict__ grad_scale, float* __restrict__ ws,
+                                                float* __restrict__ gxhat) {
+    d_sym_bwd<CB>(GridCtx{(int)blockIdx.x, (int)gridDim.x}, l, xhat, levels, prior, scaling, noise_var, scal, grad_scale, ws, gxhat);
 }
 
 // ------------------------------------------------------------------------------------------
 // equaliser backward (persistent workgroups; partial sums per workgroup)
 // ------------------------------------------------------------------------------------------
 template <int MAXI>
-__global__ __launch_bounds__(NT) void k_eq_bwd(Lay l, const float* __restrict__ y, const float* __restrict__ gx,
+__device__ __forceinline__ void d_eq_bwd(const GridCtx gc, Lay l, const float* __restrict__ y, const float* __restrict__ gx,
                                                float* __restrict__ ws) {
     extern __shared__ float sm[];
     float* tile = sm;
@@ -576,7 +613,7 @@ __global__ __launch_bounds__(NT) void k_eq_bwd(Lay l, const float* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[s][e] = 0.f;
     float acc1[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int t = blockIdx.x; t < l.ntile_eq; t += gridDim.x) {
+    for (int t = gc.bid; t < l.ntile_eq; t += gc.nb) {
         const int64_t b0 = l.own_lo + (int64_t)t * EQ_TB;
         const int64_t rem = l.own_lo + l.own_cnt - b0;
         const int nbs = rem < EQ_TB ? (int)rem : EQ_TB;
@@ -635,7 +672,7 @@ __global__ __launch_bounds__(NT) void k_eq_bwd(Lay l, const float* __restrict__ 
         }
     }
     // flush
-    float* part = ws + l.o_part_eq + (int64_t)blockIdx.x * l.rec_eq;
+    float* part = ws + l.o_part_eq + (int64_t)gc.bid * l.rec_eq;
     __syncthreads();
     if (l.nitems_eq > 0) {
         if (MAXI == 1 && l.nitems_eq <= NT) {
@@ -674,11 +711,17 @@ __global__ __launch_bounds__(NT) void k_eq_bwd(Lay l, const float* __restrict__ 
     }
 }
 
+template <int MAXI>
+__global__ __launch_bounds__(NT) void k_eq_bwd(Lay l, const float* __restrict__ y, const float* __restrict__ gx,
+                                               float* __restrict__ ws) {
+    d_eq_bwd<MAXI>(GridCtx{(int)blockIdx.x, (int)gridDim.x}, l, y, gx, ws);
+}
+
 // ------------------------------------------------------------------------------------------
 // fused ELBO forward + backward over sliding windows (polyphase form)
 // ------------------------------------------------------------------------------------------
 template <int MAXI>
-__global__ __launch_bounds__(NT) void k_elbo(Lay l, const float* __restrict__ y, float* __restrict__ ws) {
+__device__ __forceinline__ void d_elbo(const GridCtx gc, Lay l, const float* __restrict__ y, float* __restrict__ ws) {
     extern __shared__ float sm[];
     const int TW = l.TWIN, TSYM = l.TSYM, LTp = l.LTp, NS = l.ns, NG = l.NG;
     float* s_mom = sm;                       // [NS][4][TSYM]
@@ -725,7 +768,7 @@ __global__ __launch_bounds__(NT) void k_elbo(Lay l, const float* __restrict__ y,
             for (int e = 0; e < 16; ++e) acc[s][e] = 0.f;
         double v1 = 0.0, v2 = 0.0, v3 = 0.0;  // gh1, gd, gdq of vector item (o,k) = tid
 
-        for (int tile = blockIdx.x; tile < l.ntile_elbo; tile += gridDim.x) {
+        for (int tile = gc.bid; tile < l.ntile_elbo; tile += gc.nb) {
             const int64_t s0 = l.own_lo + (int64_t)tile * l.TS;
             const int64_t s1 = (s0 + l.TS < own_hi) ? s0 + l.TS : own_hi;
             const int64_t tbase = s0 - l.kmax;
@@ -746,7 +789,7 @@ __global__ __launch_bounds__(NT) void k_elbo(Lay l, const float* __restrict__ y,
                     float v = 0.f;
                     if (valid) {
                         const int64_t loc = l.pre + n - l.y_lo;
-                        if (loc >= 0 && loc < l.y_len) v = y[(int64_t)o * l.y_len + loc];
+                        if (loc >= 0 && loc < l.y_len) v = y[(int64_t)o * l.y_stride + loc];
                     }
                     s_yw[o * TW + tid] = v;
                 }
@@ -932,7 +975,7 @@ __global__ __launch_bounds__(NT) void k_elbo(Lay l, const float* __restrict__ y,
             }
         }
         // ---- flush this phase's partial sums
-        float* part = ws + l.o_part_elbo + (int64_t)blockIdx.x * l.rec_elbo + (size_t)r * rec_elbo_phase(l);
+        float* part = ws + l.o_part_elbo + (int64_t)gc.bid * l.rec_elbo + (size_t)r * rec_elbo_phase(l);
         float* partG = part;
         float* partP = part + NS * LTp * LTp;
         float* partV = partP + LTp * LTp;
@@ -983,13 +1026,18 @@ __global__ __launch_bounds__(NT) void k_elbo(Lay l, const float* __restrict__ y,
         }
     }
     const double s = block_sum_double(Eacc, dred);
-    if (tid == 0) reinterpret_cast<double*>(ws + l.o_Epart)[blockIdx.x] = s;
+    if (tid == 0) reinterpret_cast<double*>(ws + l.o_Epart)[gc.bid] = s;
+}
+
+template <int MAXI>
+__global__ __launch_bounds__(NT) void k_elbo(Lay l, const float* __restrict__ y, float* __restrict__ ws) {
+    d_elbo<MAXI>(GridCtx{(int)blockIdx.x, (int)gridDim.x}, l, y, ws);
 }
 
 // ------------------------------------------------------------------------------------------
 // reductions, chain rules, optimiser
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_reduce_scalars(Lay l, const float* __restrict__ ws, double* __restrict__ scal) {
+__device__ __forceinline__ void d_reduce_scalars(const GridCtx gc, Lay l, const float* __restrict__ ws, double* __restrict__ scal) {
     __shared__ double red[NT / 64];
     const double* Ep = reinterpret_cast<const double*>(ws + l.o_Epart);
     const double* Kp = reinterpret_cast<const double*>(ws + l.o_KLpart);
@@ -1001,8 +1049,12 @@ __global__ __launch_bounds__(NT) void k_reduce_scalars(Lay l, const float* __res
     if (threadIdx.x == 0) { scal[V2VAE_SCAL_E] = es; scal[V2VAE_SCAL_KL] = ks; }
 }
 
-__global__ void k_finalize_scalars(double W, double* __restrict__ scal) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
+__global__ __launch_bounds__(NT) void k_reduce_scalars(Lay l, const float* __restrict__ ws, double* __restrict__ scal) {
+    d_reduce_scalars(GridCtx{(int)blockIdx.x, (int)gridDim.x}, l, ws, scal);
+}
+
+__device__ __forceinline__ void d_finalize_scalars(const GridCtx gc, double W, double* __restrict__ scal) {
+    if (threadIdx.x == 0 && gc.bid == 0) {
         const double E = scal[V2VAE_SCAL_E];
         scal[V2VAE_SCAL_LOSS] = scal[V2VAE_SCAL_KL] + W * log(E);
         scal[V2VAE_SCAL_LAMBDA] = W / E;
@@ -1010,16 +1062,40 @@ __global__ void k_finalize_scalars(double W, double* __restrict__ scal) {
     }
 }
 
+__global__ void k_finalize_scalars(double W, double* __restrict__ scal) {
+    d_finalize_scalars(GridCtx{(int)blockIdx.x, (int)gridDim.x}, W, scal);
+}
+
 // records [first, first + per) of `part` summed into out[blockIdx.y][.] (fixed order, double accumulation)
+__device__ __forceinline__ void d_sum_records(const GridCtx gc, int chunk, const float* __restrict__ part, int rec, int nrec,
+                                              int per, float* __restrict__ out) {
+    const int first = chunk * per;
+    const int last = first + per < nrec ? first + per : nrec;
+    for (int i = gc.bid * NT + threadIdx.x; i < rec; i += gc.nb * NT) {
+        double s = 0.0;
+        for (int b = first; b < last; ++b) s += (double)part[(size_t)b * rec + i];
+        out[(size_t)chunk * rec + i] = (float)s;
+    }
+}
+
 __global__ __launch_bounds__(NT) void k_sum_records(const float* __restrict__ part, int rec, int nrec, int per,
                                                     float* __restrict__ out) {
-    const int i = blockIdx.x * NT + threadIdx.x;
-    if (i >= rec) return;
-    const int first = blockIdx.y * per;
-    const int last = first + per < nrec ? first + per : nrec;
-    double s = 0.0;
-    for (int b = first; b < last; ++b) s += (double)part[(size_t)b * rec + i];
-    out[(size_t)blockIdx.y * rec + i] = (float)s;
+    d_sum_records(GridCtx{(int)blockIdx.x, (int)gridDim.x}, (int)blockIdx.y, part, rec, nrec, per, out);
+}
+
+// same two-stage order as launch_sum_records, executed by one workgroup
+__device__ __forceinline__ void d_sum_records_all(const float* part, int rec, int nrec, float* stage, float* tot) {
+    if (rec <= 0) return;
+    const GridCtx one{0, 1};
+    if (nrec <= SUM_CHUNKS) {
+        d_sum_records(one, 0, part, rec, nrec, nrec, tot);
+        return;
+    }
+    const int per = (nrec + SUM_CHUNKS - 1) / SUM_CHUNKS;
+    const int chunks = (nrec + per - 1) / per;
+    for (int c = 0; c < chunks; ++c) d_sum_records(one, c, part, rec, nrec, per, stage);
+    __syncthreads();
+    d_sum_records(one, 0, stage, rec, chunks, chunks, tot);
 }
 
 void launch_sum_records(const Lay& l, const float* part, int rec, int nrec, float* stage, float* tot, hipStream_t st) {
@@ -1062,13 +1138,13 @@ __device__ __forceinline__ float g1_value(const Lay& l, const float* __restrict_
     return V[(o * 3 + which) * l.LTp + k];
 }
 
-__global__ __launch_bounds__(NT) void k_chain_channel(Lay l, const float* __restrict__ ws, const double* __restrict__ scal,
+__device__ __forceinline__ void d_chain_channel(const GridCtx gc, Lay l, const float* __restrict__ ws, const double* __restrict__ scal,
                                                       const float* __restrict__ grad_scale, float* __restrict__ g_h1,
                                                       float* __restrict__ g_h2) {
     const float lam = (float)scal[V2VAE_SCAL_LAMBDA] * (grad_scale ? grad_scale[0] : 1.f);
     const int L = l.L;
     const int n1 = l.ns * L, n2 = l.ns * L * L;
-    for (int idx = blockIdx.x * NT + threadIdx.x; idx < n1 + n2; idx += gridDim.x * NT) {
+    for (int idx = gc.bid * NT + threadIdx.x; idx < n1 + n2; idx += gc.nb * NT) {
         if (idx < n1) {
             if (!g_h1) continue;
             float v;
@@ -1102,7 +1178,13 @@ __global__ __launch_bounds__(NT) void k_chain_channel(Lay l, const float* __rest
     }
 }
 
-__global__ __launch_bounds__(NT) void k_chain_equaliser(Lay l, const float* __restrict__ ws, float* __restrict__ g_k1,
+__global__ __launch_bounds__(NT) void k_chain_channel(Lay l, const float* __restrict__ ws, const double* __restrict__ scal,
+                                                      const float* __restrict__ grad_scale, float* __restrict__ g_h1,
+                                                      float* __restrict__ g_h2) {
+    d_chain_channel(GridCtx{(int)blockIdx.x, (int)gridDim.x}, l, ws, scal, grad_scale, g_h1, g_h2);
+}
+
+__device__ __forceinline__ void d_chain_equaliser(const GridCtx gc, Lay l, const float* __restrict__ ws, float* __restrict__ g_k1,
                                                         float* __restrict__ g_k2) {
     const float* K2t = ws + l.o_tot_eq;
     const float* K1t = K2t + (size_t)l.ns * l.LT2p * l.LT2p;
@@ -1110,7 +1192,7 @@ __global__ __launch_bounds__(NT) void k_chain_equaliser(Lay l, const float* __re
     const int n1 = l.ns * l1, n2 = l.ns * l2 * l2;
     auto K2 = [&](int o, int a, int b) { return K2t[((size_t)o * P + a) * P + b]; };
     auto K1 = [&](int o, int c, int j) { return K1t[(o * l.ns + c) * l1 + j]; };
-    for (int idx = blockIdx.x * NT + threadIdx.x; idx < n1 + n2; idx += gridDim.x * NT) {
+    for (int idx = gc.bid * NT + threadIdx.x; idx < n1 + n2; idx += gc.nb * NT) {
         if (idx < n1) {
             if (!g_k1) continue;
             float v;
@@ -1141,18 +1223,25 @@ __global__ __launch_bounds__(NT) void k_chain_equaliser(Lay l, const float* __re
     }
 }
 
-__global__ __launch_bounds__(NT) void k_copy(const float* __restrict__ src, float* __restrict__ dst, int n) {
-    const int i = blockIdx.x * NT + threadIdx.x;
-    if (i < n) dst[i] = src[i];
+__global__ __launch_bounds__(NT) void k_chain_equaliser(Lay l, const float* __restrict__ ws, float* __restrict__ g_k1,
+                                                        float* __restrict__ g_k2) {
+    d_chain_equaliser(GridCtx{(int)blockIdx.x, (int)gridDim.x}, l, ws, g_k1, g_k2);
 }
 
-__global__ __launch_bounds__(NT) void k_adam(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                             float* __restrict__ v, float* __restrict__ vmax, float w1, float beta2,
-                                             float w2, float step_size, float bc2_sqrt, float eps,
-                                             const double* __restrict__ scal, float* __restrict__ noise_var,
-                                             float* __restrict__ loss_out) {
-    const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
-    if (i < n) {
+__device__ __forceinline__ void d_copy(const GridCtx gc, const float* __restrict__ src, float* __restrict__ dst, int n) {
+    for (int i = gc.bid * NT + threadIdx.x; i < n; i += gc.nb * NT) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(NT) void k_copy(const float* __restrict__ src, float* __restrict__ dst, int n) {
+    d_copy(GridCtx{(int)blockIdx.x, (int)gridDim.x}, src, dst, n);
+}
+
+__device__ __forceinline__ void d_adam(const GridCtx gc, int64_t n, float* __restrict__ p, const float* __restrict__ g,
+                                       float* __restrict__ m, float* __restrict__ v, float* __restrict__ vmax, float w1,
+                                       float beta2, float w2, float step_size, float bc2_sqrt, float eps,
+                                       const double* __restrict__ scal, float* __restrict__ noise_var,
+                                       float* __restrict__ loss_out) {
+    for (int64_t i = (int64_t)gc.bid * NT + threadIdx.x; i < n; i += (int64_t)gc.nb * NT) {
         const float gi = g[i];
         const float mi = fmaf(w1, gi - m[i], m[i]);          // exp_avg.lerp_(grad, 1 - beta1)
         const float vi = fmaf(w2 * gi, gi, v[i] * beta2);    // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
@@ -1161,9 +1250,109 @@ __global__ __launch_bounds__(NT) void k_adam(int64_t n, float* __restrict__ p, c
         m[i] = mi; v[i] = vi; vmax[i] = vm;
         p[i] = p[i] - step_size * (mi / denom);
     }
-    if (i == 0 && scal) {
+    if (gc.bid == 0 && threadIdx.x == 0 && scal) {
         if (noise_var) noise_var[0] = (float)(scal[V2VAE_SCAL_E] / scal[V2VAE_SCAL_W]);
         if (loss_out) loss_out[0] = (float)scal[V2VAE_SCAL_LOSS];
+    }
+}
+
+__global__ __launch_bounds__(NT) void k_adam(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                             float* __restrict__ v, float* __restrict__ vmax, float w1, float beta2,
+                                             float w2, float step_size, float bc2_sqrt, float eps,
+                                             const double* __restrict__ scal, float* __restrict__ noise_var,
+                                             float* __restrict__ loss_out) {
+    d_adam(GridCtx{(int)blockIdx.x, (int)gridDim.x}, n, p, g, m, v, vmax, w1, beta2, w2, step_size, bc2_sqrt, eps, scal, noise_var,
+           loss_out);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// persistent fit: one workgroup per model runs the whole mini-batch loop
+// ------------------------------------------------------------------------------------------
+// Everything a model's workgroup reads back after writing it (tables, moments, partial records, scalars,
+// parameters, optimiser state) goes through pointers that are made opaque per-lane values here, so those reads
+// are ordinary vector loads ordered by the workgroup barriers between stages; only the never-written inputs
+// (samples, levels, prior, schedule) keep wave-uniform addresses.
+template <typename T>
+__device__ __forceinline__ T* per_lane(T* p) {
+    asm volatile("" : "+v"(p));
+    return p;
+}
+
+template <int CB, int MAXI_EQ>
+__global__ __launch_bounds__(NT) void k_fit_persistent(Lay l, v2vae_fit_args a, int64_t ws_floats, int64_t n0, int64_t n1,
+                                                       int64_t n2, int64_t n3, int64_t n4) {
+    const int m = blockIdx.x;
+    const int64_t pack = n0 + n1 + n2 + n3 + n4;
+    const int64_t B = l.sym_cnt;
+    float* ws = per_lane(reinterpret_cast<float*>(a.ws) + (int64_t)m * ws_floats);
+    float* prm = per_lane(a.params + (int64_t)m * pack);
+    float* g = per_lane(a.grads + (int64_t)m * pack);
+    float* am = per_lane(a.adam_m + (int64_t)m * pack);
+    float* av = per_lane(a.adam_v + (int64_t)m * pack);
+    float* avm = per_lane(a.adam_vmax + (int64_t)m * pack);
+    float* nv = per_lane(a.noise_var + m);
+    double* scal = per_lane(a.scal + (int64_t)m * V2VAE_SCAL_COUNT);
+    float* xh = per_lane(a.xhat + (int64_t)m * l.ns * B);
+    float* gx = per_lane(a.gxhat + (int64_t)m * l.ns * B);
+    const float* ym = a.y + (int64_t)m * a.y_model_stride;
+    float* h1 = prm;
+    float* h2 = h1 + n0;
+    float* k1 = h2 + n1;
+    float* k2 = n3 ? k1 + n2 : nullptr;
+    float* sc = k1 + n2 + n3;
+    const GridCtx one{0, 1};
+    const int nt_eqf = (int)((B + EQ_TB - 1) / EQ_TB);
+    const float w1 = (float)(1.0 - (double)a.beta1), w2 = (float)(1.0 - (double)a.beta2);
+    const int64_t nadam = n0 + n1 + n2 + n3 + (a.learn_scaling ? n4 : 0);
+    for (int n = 0; n < a.n_batches; ++n) {
+        const float* yb = ym + (int64_t)n * B * l.S;
+        d_prep_tables(one, l, h1, h2, k1, k2, ws);
+        __syncthreads();
+        for (int t = 0; t < nt_eqf; ++t) {
+            d_eq_fwd(GridCtx{t, nt_eqf}, l, yb, ws, xh);
+            __syncthreads();
+        }
+        for (int b = 0; b < l.nblk_sym; ++b) {
+            d_demap_moments<CB>(GridCtx{b, l.nblk_sym}, l, xh, a.levels, a.prior, sc, nv, ws, nullptr);
+            __syncthreads();
+        }
+        for (int b = 0; b < l.nblk_elbo; ++b) {
+            d_elbo<1>(GridCtx{b, l.nblk_elbo}, l, yb, ws);
+            __syncthreads();
+        }
+        d_reduce_scalars(one, l, ws, scal);
+        __syncthreads();
+        d_finalize_scalars(one, (double)l.W, scal);
+        __syncthreads();
+        for (int b = 0; b < l.nblk_sym; ++b) {
+            d_sym_bwd<CB>(GridCtx{b, l.nblk_sym}, l, xh, a.levels, a.prior, sc, nv, scal, nullptr, ws, gx);
+            __syncthreads();
+        }
+        for (int b = 0; b < l.nblk_eq; ++b) {
+            d_eq_bwd<MAXI_EQ>(GridCtx{b, l.nblk_eq}, l, yb, gx, ws);
+            __syncthreads();
+        }
+        d_sum_records_all(ws + l.o_part_elbo, l.rec_elbo, l.nblk_elbo, ws + l.o_sumstage, ws + l.o_tot_elbo);
+        __syncthreads();
+        d_chain_channel(one, l, ws, scal, nullptr, g, g + n0);
+        d_sum_records_all(ws + l.o_part_sym, l.rec_sym, l.nblk_sym, ws + l.o_sumstage, ws + l.o_tot_sym);
+        __syncthreads();
+        d_copy(one, ws + l.o_tot_sym, g + n0 + n1 + n2 + n3, l.rec_sym);
+        d_sum_records_all(ws + l.o_part_eq, l.rec_eq, l.nblk_eq, ws + l.o_sumstage, ws + l.o_tot_eq);
+        __syncthreads();
+        d_chain_equaliser(one, l, ws, g + n0 + n1, n3 ? g + n0 + n1 + n2 : nullptr);
+        __syncthreads();
+        d_adam(one, nadam, prm, g, am, av, avm, w1, a.beta2, w2, a.step_size[n], a.bc2_sqrt[n], a.eps, scal,
+               a.adaptive_noise ? nv : nullptr, a.loss_curve ? a.loss_curve + (int64_t)m * a.n_batches + n : nullptr);
+        if (a.y_eq) {
+            const int64_t tot = (int64_t)a.n_batches * B;
+            for (int idx = threadIdx.x; idx < l.ns * B; idx += NT) {
+                const int c = idx / (int)B, i = idx - c * (int)B;
+                a.y_eq[((int64_t)m * l.ns + c) * tot + (int64_t)n * B + i] = xh[idx];
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -1440,6 +1629,62 @@ int v2vae_train_step(const v2vae_problem* p, const v2vae_train_args* a, void* st
     const int64_t nadam = n[0] + n[1] + n[2] + n[3] + (a->learn_scaling ? n[4] : 0);
     return v2vae_adam_amsgrad(nadam, a->params, g, a->adam_m, a->adam_v, a->adam_vmax, a->lr, a->beta1, a->beta2, a->eps,
                               a->step, a->scal, a->adaptive_noise ? a->noise_var : nullptr, a->loss_out, stream);
+}
+
+int v2vae_adam_schedule(int64_t step0, int64_t n, const float* lr, float beta1, float beta2, float* step_size,
+                        float* bc2_sqrt) {
+    if (step0 < 0 || n < 1 || !lr || !step_size || !bc2_sqrt) return V2VAE_EINVAL;
+    for (int64_t i = 0; i < n; ++i) {
+        const double step = (double)(step0 + i + 1);
+        const double bc1 = 1.0 - pow((double)beta1, step);
+        const double bc2 = 1.0 - pow((double)beta2, step);
+        step_size[i] = (float)((double)lr[i] / bc1);
+        bc2_sqrt[i] = (float)sqrt(bc2);
+    }
+    return V2VAE_OK;
+}
+
+int v2vae_fit_persistent(const v2vae_problem* p, const v2vae_fit_args* a, void* stream) {
+    if (!p || !a) return V2VAE_EINVAL;
+    Lay l;
+    int rc = make_layout(p, &l);
+    if (rc) return rc;
+    // one batch, described as a whole sequence
+    if (l.y_lo != 0 || l.sym_lo != 0 || l.own_lo != 0 || l.y_len != l.n_glob || l.sym_cnt != l.b_glob || l.own_cnt != l.b_glob)
+        return V2VAE_EINVAL;
+    if (a->n_models < 1 || a->n_batches < 1 || !a->y || !a->levels || !a->prior || !a->params || !a->grads || !a->adam_m ||
+        !a->adam_v || !a->adam_vmax || !a->noise_var || !a->ws || !a->scal || !a->xhat || !a->gxhat || !a->step_size ||
+        !a->bc2_sqrt)
+        return V2VAE_EINVAL;
+    if (a->y_stream_stride < (int64_t)a->n_batches * l.n_glob || a->y_model_stride < 0) return V2VAE_EINVAL;
+    if (l.maxi_elbo != 1 || l.maxi_eq > 2) return V2VAE_ESIZE;
+    l.use_cx = 0;
+    l.use_eqcx = 0;
+    l.nblk_E = l.nblk_elbo;
+    l.y_stride = a->y_stream_stride;
+    int64_t n[5];
+    v2vae_pack_sizes(p, n);
+    const int lds = l.lds_elbo > l.lds_eq ? l.lds_elbo : l.lds_eq;
+    hipStream_t st = (hipStream_t)stream;
+#define V2VAE_LAUNCH_FIT(CB, ME)                                                                                       \
+    do {                                                                                                               \
+        rc = allow_lds(k_fit_persistent<CB, ME>, lds);                                                                 \
+        if (rc) return rc;                                                                                             \
+        hipLaunchKernelGGL((k_fit_persistent<CB, ME>), dim3(a->n_models), dim3(NT), lds, st, l, *a, l.total_floats,    \
+                           n[0], n[1], n[2], n[3], n[4]);                                                              \
+    } while (0)
+#define V2VAE_LAUNCH_FIT_C(ME)                   \
+    do {                                         \
+        if (l.C <= 2) V2VAE_LAUNCH_FIT(2, ME);   \
+        else if (l.C <= 4) V2VAE_LAUNCH_FIT(4, ME); \
+        else if (l.C <= 8) V2VAE_LAUNCH_FIT(8, ME); \
+        else V2VAE_LAUNCH_FIT(16, ME);           \
+    } while (0)
+    if (l.maxi_eq == 1) V2VAE_LAUNCH_FIT_C(1);
+    else V2VAE_LAUNCH_FIT_C(2);
+#undef V2VAE_LAUNCH_FIT_C
+#undef V2VAE_LAUNCH_FIT
+    return launch_status();
 }
 
 }  // extern "C"

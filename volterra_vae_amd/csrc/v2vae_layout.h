@@ -33,6 +33,7 @@ constexpr int CX_BLOCKS = 256;       // one workgroup per CU (the LDS image take
 struct Lay {
     int ns, mode, S, l1, pad1, l2, L, C;
     int64_t n_glob, y_lo, y_len, sym_lo, sym_cnt, own_lo, own_cnt;
+    int64_t y_stride;  // floats between the ns sample streams (y_len unless a batch is a slice of a longer sequence)
     int pre;                 // (L-1)/2: y' = y[pre + n]
     int64_t b_glob, W, kl_lo, kl_hi;
     int kmax, LE, LEp, LTp;  // compact channel taps per phase

@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import Problem, TrainArgs, check, lib
+from ._lib import FitArgs, Problem, TrainArgs, check, lib
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -127,6 +127,80 @@ def adam_amsgrad_(params, grads, m, v, vmax, lr, step, beta1=0.9, beta2=0.999, e
     n = params.numel() if n is None else n
     check(lib.v2vae_adam_amsgrad(n, _ptr(params), _ptr(grads), _ptr(m), _ptr(v), _ptr(vmax), lr, beta1, beta2, eps, step,
                                  _ptr(scal), _ptr(noise_var), _ptr(loss_out), _stream()), "v2vae_adam_amsgrad")
+
+
+def adam_schedule(lrs, step0=0, beta1=0.9, beta2=0.999):
+    """Per-step (step_size, bc2_sqrt) float32 host arrays for steps step0+1.. with learning rates `lrs`."""
+    import numpy as np
+    lr = np.ascontiguousarray(lrs, dtype=np.float32)
+    ss, bc = np.empty_like(lr), np.empty_like(lr)
+    check(lib.v2vae_adam_schedule(step0, lr.size, lr.ctypes.data, beta1, beta2, ss.ctypes.data, bc.ctypes.data),
+          "v2vae_adam_schedule")
+    return ss, bc
+
+
+class PersistentFit:
+    """n_models independent models, each trained over n_batches sequential mini-batches in ONE kernel launch
+    (one workgroup per model): the mini-batch loop of lib/real_equalization.py:482-502 without a launch or a
+    host round trip per batch.  All state tensors carry a leading model dimension."""
+
+    def __init__(self, *, ns, sps, l1, pad1, l2, L, C_levels, batch_symbols, n_models, device):
+        p = Problem()
+        p.ns, p.mode, p.sps, p.l1, p.pad1, p.l2, p.L, p.C = ns, (0 if ns == 1 else 1), sps, l1, pad1, l2, L, C_levels
+        p.n_glob = p.y_len = batch_symbols * sps
+        p.y_lo = p.sym_lo = p.own_lo = 0
+        p.sym_cnt = p.own_cnt = batch_symbols
+        check(lib.v2vae_check_problem(C.byref(p)), "v2vae_check_problem")
+        self.p, self.device, self.n_models, self.B = p, device, n_models, batch_symbols
+        self.sizes = _lib.pack_sizes(p)
+        self.pack = sum(self.sizes)
+        nfl = (lib.v2vae_workspace_bytes(C.byref(p)) + 3) // 4
+        self.ws = torch.zeros((n_models, nfl), dtype=torch.float32, device=device)
+        self.scal = torch.zeros((n_models, _lib.SCAL_COUNT), dtype=torch.float64, device=device)
+        self.xhat = torch.zeros((n_models, ns, batch_symbols), dtype=torch.float32, device=device)
+        self.gxhat = torch.zeros_like(self.xhat)
+
+    def run(self, *, y, levels, prior, params, grads, adam_m, adam_v, adam_vmax, noise_var, lrs, step0=0,
+            y_eq=None, loss_curve=None, beta1=0.9, beta2=0.999, eps=1e-8, learn_scaling=True, adaptive_noise=True):
+        """y: [ns, T] (shared by all models) or [n_models, ns, T], T >= n_batches * B * sps; lrs: one learning
+        rate per batch (its length is the number of batches); params & co: [n_models, pack]."""
+        nb = len(lrs)
+        p = self.p
+        for name, t in (("y", y), ("params", params), ("grads", grads), ("adam_m", adam_m), ("adam_v", adam_v),
+                        ("adam_vmax", adam_vmax), ("noise_var", noise_var), ("levels", levels), ("prior", prior)):
+            _require_gpu_f32(t, name)
+        if y.dim() == 3 and y.shape[0] != self.n_models:
+            raise ValueError("y: leading dimension must be n_models")
+        if y.shape[-2] != p.ns or y.shape[-1] < nb * self.B * p.sps:
+            raise ValueError(f"y: expected [..., {p.ns}, >= {nb * self.B * p.sps}], got {tuple(y.shape)}")
+        for name, t in (("params", params), ("grads", grads), ("adam_m", adam_m), ("adam_v", adam_v), ("adam_vmax", adam_vmax)):
+            if tuple(t.shape) != (self.n_models, self.pack):
+                raise ValueError(f"{name}: expected {(self.n_models, self.pack)}, got {tuple(t.shape)}")
+        if noise_var.numel() != self.n_models:
+            raise ValueError("noise_var: one value per model")
+        if y_eq is not None and tuple(y_eq.shape) != (self.n_models, p.ns, nb * self.B):
+            raise ValueError(f"y_eq: expected {(self.n_models, p.ns, nb * self.B)}")
+        if loss_curve is not None and tuple(loss_curve.shape) != (self.n_models, nb):
+            raise ValueError(f"loss_curve: expected {(self.n_models, nb)}")
+        ss, bc = adam_schedule(lrs, step0, beta1, beta2)
+        sched = torch.from_numpy(__import__("numpy").stack((ss, bc))).to(self.device)
+        a = FitArgs()
+        a.y = y.data_ptr()
+        a.y_model_stride = y.shape[-2] * y.shape[-1] if y.dim() == 3 else 0
+        a.y_stream_stride = y.shape[-1]
+        a.levels, a.prior = levels.data_ptr(), prior.data_ptr()
+        a.params, a.grads = params.data_ptr(), grads.data_ptr()
+        a.adam_m, a.adam_v, a.adam_vmax = adam_m.data_ptr(), adam_v.data_ptr(), adam_vmax.data_ptr()
+        a.noise_var, a.ws, a.scal = noise_var.data_ptr(), self.ws.data_ptr(), self.scal.data_ptr()
+        a.xhat, a.gxhat = self.xhat.data_ptr(), self.gxhat.data_ptr()
+        a.y_eq = 0 if y_eq is None else y_eq.data_ptr()
+        a.loss_curve = 0 if loss_curve is None else loss_curve.data_ptr()
+        a.step_size, a.bc2_sqrt = sched[0].data_ptr(), sched[1].data_ptr()
+        a.beta1, a.beta2, a.eps = beta1, beta2, eps
+        a.n_models, a.n_batches = self.n_models, nb
+        a.learn_scaling, a.adaptive_noise = int(learn_scaling), int(adaptive_noise)
+        check(lib.v2vae_fit_persistent(C.byref(p), C.byref(a), _stream()), "v2vae_fit_persistent")
+        self._keep = sched  # the launch is asynchronous: keep the schedule alive until the next call
 
 
 # ------------------------------------------------------------------------------------------------

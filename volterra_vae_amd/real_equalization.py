@@ -20,7 +20,8 @@ import numpy as np
 import torch
 
 from . import ops
-from .ops import ElboLossFn, Plan
+from ._lib import V2VAEError
+from .ops import ElboLossFn, PersistentFit, Plan
 from .torch_components import SecondOrderVolterraSeries, StridedFIREqualiser, _check_dtype, _resolve_device
 
 
@@ -287,8 +288,28 @@ class VAESecondVolterraForward(GenericTorchBlindProbabilisticEqualizer):
         if self.learnable_noise_scaling:
             self.noise_scaling.grad = None
 
+    # True: fit() runs the whole mini-batch loop as ONE persistent kernel launch (one workgroup) when the shape allows;
+    # False: one fused kernel sequence per batch.  Bitwise identical results.  A single model on a single workgroup
+    # leaves the other 255 compute units idle and measures slower than the per-batch sequence (456 vs 172 us per
+    # 500-symbol step), so the default is False; sweeps of many models use the persistent kernel (ops.PersistentFit).
+    persistent_fit = False
+
+    def _persistent(self, B):
+        key = ("persistent", B)
+        if key not in self._plans:
+            l1, l2 = self._eq_sizes
+            try:
+                self._plans[key] = PersistentFit(ns=1, sps=self.samples_per_symbol, l1=l1, pad1=self._pad1(), l2=l2,
+                                                 L=self.channel_memory, C_levels=self.constellation_size,
+                                                 batch_symbols=B, n_models=1, device=self.torch_device)
+            except V2VAEError:
+                self._plans[key] = None
+        return self._plans[key]
+
     def fit(self, y_input):
-        """Mini-batch training loop of lib/real_equalization.py:461-504, one fused kernel sequence per batch."""
+        """Mini-batch training loop of lib/real_equalization.py:461-504.  Small batches: the whole loop is one
+        persistent kernel launch (the per-batch loss lines are then printed after the launch has finished);
+        otherwise one fused kernel sequence per batch."""
         n_batches = self._check_input(y_input)
         if self.optimizer is None:
             raise Exception("Optimizer has not been initialized yet. Please call 'initialize_optimizer' before proceeding to 'fit'.")
@@ -299,8 +320,27 @@ class VAESecondVolterraForward(GenericTorchBlindProbabilisticEqualizer):
         losses = torch.zeros(max(n_batches, 1), dtype=torch.float32, device=self.torch_device)
         opt = self.optimizer
         opt._opt_called = True  # the fused step below is the optimizer step
-        plan = self._plan(B * S) if n_batches else None
         levels, prior = self._levels2d(), self.constellation_prior.view(1, -1).contiguous()
+        pf = self._persistent(B) if (self.persistent_fit and n_batches and B <= self.PERSISTENT_MAX_BATCH) else None
+        if pf is not None:
+            lrs, shown = [], []
+            for n in range(n_batches):
+                lrs.append(opt.current_lr())
+                shown.append(lr_schedule.get_last_lr()[-1] if self.lr_schedule else self.learning_rate)
+                if lr_schedule:
+                    lr_schedule.step()
+            yq = torch.zeros((1, 1, n_batches * B), dtype=y.dtype, device=self.torch_device)
+            pf.run(y=y.view(1, -1), levels=levels, prior=prior, params=self._pack.view(1, -1), grads=opt.flat_grad.view(1, -1),
+                   adam_m=opt.exp_avg.view(1, -1), adam_v=opt.exp_avg_sq.view(1, -1), adam_vmax=opt.max_exp_avg_sq.view(1, -1),
+                   noise_var=self._noise_var, lrs=lrs, step0=opt.step_count, y_eq=yq, loss_curve=losses[:n_batches].view(1, -1),
+                   learn_scaling=self.learnable_noise_scaling, adaptive_noise=self.adaptive_noise_variance)
+            opt.step_count += n_batches
+            y_eq[:n_batches * B] = yq.view(-1)
+            loss_curve = losses[:n_batches].cpu().numpy().astype(np.float64)
+            for n in range(0, n_batches, self.loss_print_interval):
+                print(f"Batch {n}, Loss: {loss_curve[n]:.3f} (LR: {shown[n]:.3e})")
+            return y_eq.cpu().numpy(), loss_curve
+        plan = self._plan(B * S) if n_batches else None
         for n in range(n_batches):
             ysl = y[n * B * S:(n + 1) * B * S].view(1, -1)
             lr_now = opt.current_lr()
@@ -316,6 +356,9 @@ class VAESecondVolterraForward(GenericTorchBlindProbabilisticEqualizer):
                 lr_schedule.step()
         loss_curve = losses[:n_batches].cpu().numpy().astype(np.float64)
         return y_eq.cpu().numpy(), loss_curve
+
+    # largest batch (symbols) trained by one workgroup; above it the many-workgroup kernels win
+    PERSISTENT_MAX_BATCH = 4096
 
     def print_model_parameters(self):
         print(f"Equaliser: {self.equaliser}")
