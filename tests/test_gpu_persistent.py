@@ -22,7 +22,8 @@ def _model(g, persistent):
 
 
 @pytest.mark.parametrize("case", ["cfg1", "cfg3", "lin"])
-def test_persistent_fit_is_bitwise_the_per_batch_fit(case):
+def test_persistent_fit_is_bitwise_the_per_batch_fit(case, monkeypatch):
+    monkeypatch.setenv("V2VAE_FORCE_GENERIC", "1")  # the stage-by-stage persistent kernel, not the on-chip one
     g = np.load(os.path.join(GOLDEN, f"v2vae_real_fit_{case}_f32.npz"))
     a, b = _model(g, True), _model(g, False)
     ya, la = a.fit(g["rx"])
@@ -39,6 +40,53 @@ def test_persistent_fit_is_bitwise_the_per_batch_fit(case):
     ya, la = a.fit(g["rx"])
     yb, lb = b.fit(g["rx"])
     assert np.array_equal(ya, yb) and np.array_equal(la, lb) and torch.equal(a._pack, b._pack)
+
+
+def _rel(a, b):
+    a = np.asarray(a.detach().cpu() if torch.is_tensor(a) else a, dtype=np.float64).reshape(-1)
+    b = np.asarray(b.detach().cpu() if torch.is_tensor(b) else b, dtype=np.float64).reshape(-1)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.mark.parametrize("case", ["cfg1", "cfg3", "lin"])
+def test_on_chip_fit_matches_per_batch_fit_and_reference(case):
+    """Small real shapes run the whole fit inside one workgroup (different summation order, same mathematics):
+    20 dependent Adam steps must stay within fp32 rounding of the per-batch kernels and of the reference run."""
+    g = np.load(os.path.join(GOLDEN, f"v2vae_real_fit_{case}_f32.npz"))
+    g64 = np.load(os.path.join(GOLDEN, f"v2vae_real_fit_{case}_f64.npz"))
+    a, b = _model(g, True), _model(g, False)
+    ya, la = a.fit(g["rx"])
+    yb, lb = b.fit(g["rx"])
+    assert not np.array_equal(ya, yb) or case == "never", "expected the on-chip kernel, got the bitwise-equal generic one"
+    for name, x, y in (("y_eq", ya, yb), ("loss", la, lb), ("h1", a.channel_h1, b.channel_h1),
+                       ("scaling", a.noise_scaling, b.noise_scaling), ("nv", a._noise_var, b._noise_var)):
+        assert _rel(x, y) < 2e-5, (name, _rel(x, y))
+    assert _rel(a.channel_h2, b.channel_h2) < 2e-4
+    assert _rel(a._pack, b._pack) < 5e-5
+    # against the reference's own fp64 run, with the reference's fp32-vs-fp64 spread as the yardstick
+    for key, ours, tol in (("loss_curve", la, 1e-5), ("y_eq", ya, 1e-5), ("h1", a.channel_h1, 1e-5), ("h2", a.channel_h2, 1e-4)):
+        own = _rel(g[key], g64[key])
+        assert _rel(ours, g64[key]) < tol + own, (key, _rel(ours, g64[key]), own)
+
+
+def test_on_chip_fit_long_batches_and_phases():
+    """Batches longer than one window chunk, three samples per symbol, even channel length."""
+    from volterra_vae_amd.real_equalization import SecondVolterraV2VAE
+    from volterra_vae_amd.synth import nonlinear_isi, pam_constellation
+    const = pam_constellation(4)
+    for S, B, L, l1, l2 in ((3, 700, 12, 13, 9), (1, 300, 8, 7, 7), (2, 1100, 14, 31, 31)):
+        rx, _ = nonlinear_isi(12 * B, const, S, 17.0, np.random.default_rng(S))
+        ms = []
+        for persistent in (True, False):
+            m = SecondVolterraV2VAE(channel_memory=L, learning_rate=3e-3, constellation=const, samples_per_symbol=S, batch_size=B,
+                                    noise_variance=0.1, torch_device=torch.device("cuda"), equaliser_n_lags1=l1,
+                                    equaliser_n_lags2=l2)
+            m.persistent_fit = persistent
+            m.initialize_optimizer()
+            ms.append((m,) + m.fit(rx))
+        (a, ya, la), (b, yb, lb) = ms
+        assert _rel(ya, yb) < 2e-5 and _rel(la, lb) < 2e-5, (S, B, _rel(ya, yb), _rel(la, lb))
+        assert _rel(a._pack, b._pack) < 1e-4, (S, B, _rel(a._pack, b._pack))
 
 
 def test_sweep_of_models_equals_individual_fits():

@@ -13,6 +13,7 @@
 #include <stdlib.h>
 
 #include "v2vae_layout.h"
+#include "v2vae_posterior.h"
 
 namespace v2vae {
 
@@ -389,53 +390,6 @@ __global__ __launch_bounds__(NT) void k_eq_fwd(Lay l, const float* __restrict__ 
 // ------------------------------------------------------------------------------------------
 // soft demapping, moments, KL
 // ------------------------------------------------------------------------------------------
-struct Posterior {
-    float q[MAX_C];
-    float mu, var, kap, gam;
-};
-
-template <int CB>
-__device__ __forceinline__ void posterior(float x, const float* __restrict__ lv, const float* __restrict__ sc, int C,
-                                          float nv, Posterior& p) {
-    // Logits reach |z| ~ 1e2..1e3 for small noise variance; rounding them to fp32 before the max is
-    // subtracted would put ~|z| * 6e-8 of absolute error into the exponent, i.e. that much RELATIVE
-    // error into q.  The difference z - max is therefore formed in double and only then rounded.
-    double zd[MAX_C];
-    double mx = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < CB; ++i)
-        if (i < C) {
-            const double d = (double)x - (double)lv[i];
-            zd[i] = -(d * d) / ((double)nv * (double)sc[i]);
-            mx = fmax(mx, zd[i]);
-        }
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < CB; ++i)
-        if (i < C) {
-            p.q[i] = expf((float)(zd[i] - mx));
-            sum += p.q[i];
-        }
-    const float inv = 1.f / sum;
-    float mu = 0.f;
-#pragma unroll
-    for (int i = 0; i < CB; ++i)
-        if (i < C) {
-            p.q[i] *= inv;
-            mu = fmaf(p.q[i], lv[i], mu);
-        }
-    float v = 0.f, k3 = 0.f, c4 = 0.f;
-#pragma unroll
-    for (int i = 0; i < CB; ++i)
-        if (i < C) {
-            const float d = lv[i] - mu, d2 = d * d;
-            v = fmaf(p.q[i], d2, v);
-            k3 = fmaf(p.q[i], d2 * d, k3);
-            c4 = fmaf(p.q[i], d2 * d2, c4);
-        }
-    p.mu = mu; p.var = v; p.kap = k3; p.gam = c4 - 3.f * v * v;
-}
-
 template <int CB>
 __device__ __forceinline__ void d_demap_moments(const GridCtx gc, Lay l, const float* __restrict__ xhat, const float* __restrict__ levels,
                                                       const float* __restrict__ prior, const float* __restrict__ scaling,
@@ -1657,15 +1611,20 @@ int v2vae_fit_persistent(const v2vae_problem* p, const v2vae_fit_args* a, void* 
         !a->bc2_sqrt)
         return V2VAE_EINVAL;
     if (a->y_stream_stride < (int64_t)a->n_batches * l.n_glob || a->y_model_stride < 0) return V2VAE_EINVAL;
+    int64_t n[5];
+    v2vae_pack_sizes(p, n);
+    hipStream_t st = (hipStream_t)stream;
+    l.y_stride = a->y_stream_stride;
+    {
+        const int took = launch_fit_rs(l, a, n, st);  // small real shapes: everything on chip
+        if (took < 0) return took;
+        if (took == 1) return launch_status();
+    }
     if (l.maxi_elbo != 1 || l.maxi_eq > 2) return V2VAE_ESIZE;
     l.use_cx = 0;
     l.use_eqcx = 0;
     l.nblk_E = l.nblk_elbo;
-    l.y_stride = a->y_stream_stride;
-    int64_t n[5];
-    v2vae_pack_sizes(p, n);
     const int lds = l.lds_elbo > l.lds_eq ? l.lds_elbo : l.lds_eq;
-    hipStream_t st = (hipStream_t)stream;
 #define V2VAE_LAUNCH_FIT(CB, ME)                                                                                       \
     do {                                                                                                               \
         rc = allow_lds(k_fit_persistent<CB, ME>, lds);                                                                 \

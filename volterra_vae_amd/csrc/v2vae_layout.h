@@ -83,4 +83,7 @@ int launch_eq_fwd_cx(const Lay& l, const float* y, const float* ws, float* xhat,
 int launch_eq_bwd_cx(const Lay& l, const float* y, const float* gx, float* ws, hipStream_t st);
 void launch_finish_equaliser_cx(const Lay& l, float* ws, float* g_k1, float* g_k2, hipStream_t st);
 
+// v2vae_fit_rs.hip: whole fit loop on chip for small real shapes; 1 = launched, 0 = shape not covered, < 0 = error
+int launch_fit_rs(const Lay& l, const v2vae_fit_args* a, const int64_t n[5], hipStream_t st);
+
 }  // namespace v2vae

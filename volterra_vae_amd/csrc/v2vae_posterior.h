@@ -1,0 +1,60 @@
+// Soft demapper shared by every kernel that needs the per-symbol posterior and its central moments
+// (lib/real_equalization.py:816-823 and the moment sums of :851-866).
+#ifndef V2VAE_POSTERIOR_H
+#define V2VAE_POSTERIOR_H
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "v2vae_layout.h"
+
+namespace v2vae {
+
+struct Posterior {
+    float q[MAX_C];
+    float mu, var, kap, gam;
+};
+
+template <int CB>
+__device__ __forceinline__ void posterior(float x, const float* __restrict__ lv, const float* __restrict__ sc, int C,
+                                          float nv, Posterior& p) {
+    // Logits reach |z| ~ 1e2..1e3 for small noise variance; rounding them to fp32 before the max is
+    // subtracted would put ~|z| * 6e-8 of absolute error into the exponent, i.e. that much RELATIVE
+    // error into q.  The difference z - max is therefore formed in double and only then rounded.
+    double zd[MAX_C];
+    double mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < CB; ++i)
+        if (i < C) {
+            const double d = (double)x - (double)lv[i];
+            zd[i] = -(d * d) / ((double)nv * (double)sc[i]);
+            mx = fmax(mx, zd[i]);
+        }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < CB; ++i)
+        if (i < C) {
+            p.q[i] = expf((float)(zd[i] - mx));
+            sum += p.q[i];
+        }
+    const float inv = 1.f / sum;
+    float mu = 0.f;
+#pragma unroll
+    for (int i = 0; i < CB; ++i)
+        if (i < C) {
+            p.q[i] *= inv;
+            mu = fmaf(p.q[i], lv[i], mu);
+        }
+    float v = 0.f, k3 = 0.f, c4 = 0.f;
+#pragma unroll
+    for (int i = 0; i < CB; ++i)
+        if (i < C) {
+            const float d = lv[i] - mu, d2 = d * d;
+            v = fmaf(p.q[i], d2, v);
+            k3 = fmaf(p.q[i], d2 * d, k3);
+            c4 = fmaf(p.q[i], d2 * d2, c4);
+        }
+    p.mu = mu; p.var = v; p.kap = k3; p.gam = c4 - 3.f * v * v;
+}
+
+}  // namespace v2vae
+#endif
