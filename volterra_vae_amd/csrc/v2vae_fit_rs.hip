@@ -33,8 +33,9 @@ constexpr int RS_GREC = 96;         // per-wave, per-phase record: G 8x8 | f1 8 
 typedef float rs_f16 __attribute__((ext_vector_type(16)));
 
 struct RsOff {  // LDS carve in floats
-    int y, x, gx, mom, MP, gm, GP, D, vl, H, HH, h1c, d, dq, par, grad, gred, gtot, P, misc, dbl, total;
+    int y, x, gx, mom, MP, gm, GP, D, vl, H, HH, h1c, d, dq, par, grad, gtot, P, misc, dbl, total;
     int nchunks, TS, packp;
+    int c0, o1, o2;  // equaliser sample window: X_b[i] = y[b S + c0 - i], i < 32; first-order tap j at o1 - j, lag j at o2 + j
 };
 
 static inline int rs_rup(int x, int m) { return (x + m - 1) / m * m; }
@@ -49,6 +50,13 @@ int rs_plan(const Lay& l, int64_t pack, RsOff* o) {
     r.TS = RS_NT - l.kmax;
     r.nchunks = (B + r.TS - 1) / r.TS;
     r.packp = rs_rup((int)pack, 64);
+    {
+        const int right1 = l.l1 - 1 - l.pad1;
+        r.c0 = l.l2 > 0 && l.p2 > right1 ? l.p2 : right1;
+        r.o1 = r.c0 + l.pad1;
+        r.o2 = r.c0 - l.p2;
+        if (r.o1 > 31 || (l.l2 > 0 && r.o2 + l.l2 > 32)) return 0;  // both kernels must fit one 32-sample window
+    }
     int off = 0;
     auto take = [&](int n) { int at = off; off += rs_rup(n, 4); return at; };
     r.y = take(RS_HL + N + 32 * l.S + 64);
@@ -58,7 +66,13 @@ int rs_plan(const Lay& l, int64_t pack, RsOff* o) {
     r.mom = take(4 * r.MP);
     r.GP = rs_rup(B, 4);
     r.gm = take(4 * r.GP);
-    r.D = take(3 * 8 * RS_NT);  // also the cross-wave image of the equaliser-gradient tiles (8 x 1024 floats)
+    {   // per-window gradient image of the ELBO stage; later the cross-lane reduction image (64 slots, pitch 97) and the
+        // cross-wave image of the equaliser-gradient tiles
+        int nd = 3 * 8 * RS_NT;
+        if (nd < 64 * 97) nd = 64 * 97;
+        if (nd < RS_NW * 1024 + RS_NW * 32) nd = RS_NW * 1024 + RS_NW * 32;
+        r.D = take(nd);
+    }
     r.vl = take(RS_NT);
     r.H = take(l.S * 64);
     r.HH = take(l.S * 64);
@@ -67,7 +81,6 @@ int rs_plan(const Lay& l, int64_t pack, RsOff* o) {
     r.dq = take(l.S * 8);
     r.par = take(r.packp);
     r.grad = take(r.packp);
-    r.gred = take(RS_NW * l.S * RS_GREC);
     r.gtot = take(l.S * RS_GREC);
     r.P = take(l.S * 64);
     r.misc = take(RS_NT + 64 * RS_NW);
@@ -99,6 +112,30 @@ __device__ __forceinline__ float rs_wave_reduce_transposed(float (&x)[N], int la
     return v;
 }
 
+__device__ __forceinline__ float rs_quad_xor1(float v) {  // value of lane ^ 1 (DPP quad_perm [1,0,3,2])
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float rs_quad_xor2(float v) {  // value of lane ^ 2 (DPP quad_perm [2,3,0,1])
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
+}
+
+// Two transposing butterfly steps inside each quad of lanes: afterwards x[0 .. N/4) hold, summed over the lane's quad,
+// the elements e = bit0(lane) * N/2 + bit1(lane) * N/4 + i.  Register-only (DPP), no LDS traffic.
+template <int N>
+__device__ __forceinline__ void rs_quad_fold(float (&x)[N], int lane) {
+    const bool up0 = lane & 1, up1 = lane & 2;
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) {
+        const float lo = x[i], hi = x[i + N / 2];
+        x[i] = (up0 ? hi : lo) + rs_quad_xor1(up0 ? lo : hi);
+    }
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i) {
+        const float lo = x[i], hi = x[i + N / 4];
+        x[i] = (up1 ? hi : lo) + rs_quad_xor2(up1 ? lo : hi);
+    }
+}
+
 template <int N>
 __device__ __forceinline__ int rs_transposed_index(int lane) {
     int e = 0, sft = 0;
@@ -127,9 +164,20 @@ __device__ __forceinline__ int rs_tap(const Lay& l, int r, int k) {
     return (i >= 0 && i < l.L) ? i : -1;
 }
 
+// Diagnostic builds (-DV2VAE_STAMPS) record the constant-rate wall clock (10 ns ticks) of thread 0 of model 0 at the
+// stage boundaries of the last batch into the (otherwise unused) workspace.
+#ifdef V2VAE_STAMPS
+#define RS_STAMP(i)                                                                                        \
+    do {                                                                                                   \
+        if (tid == 0 && model == 0 && n == a.n_batches - 1) reinterpret_cast<unsigned long long*>(a.ws)[i] = wall_clock64(); \
+    } while (0)
+#else
+#define RS_STAMP(i) do { } while (0)
+#endif
+
 template <int CB>
 __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args a, int n0, int n1, int n2, int n3, int n4) {
-    extern __shared__ float sm[];
+    extern __shared__ __align__(16) float sm[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int model = blockIdx.x;
     const int B = (int)l.b_glob, N = (int)l.n_glob, S = l.S, L = l.L, l1 = l.l1, l2 = l.l2, C = l.C;
@@ -151,7 +199,6 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
     float* s_dq = sm + o.dq;
     float* s_par = sm + o.par;
     float* s_grad = sm + o.grad;
-    float* s_gred = sm + o.gred;
     float* s_gtot = sm + o.gtot;
     float* s_P = sm + o.P;
     float* s_misc = sm + o.misc;
@@ -185,6 +232,7 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
 
     for (int n = 0; n < a.n_batches; ++n) {
         const float* yb = ym + (int64_t)n * N;
+        RS_STAMP(0);
         // ---- parameters and samples to LDS
 #pragma unroll
         for (int q = 0; q < RS_APT; ++q) {
@@ -194,6 +242,7 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
         for (int i = tid; i < N; i += RS_NT) s_y[RS_HL + i] = yb[i];
         __syncthreads();
 
+        RS_STAMP(1);
         // ---- channel tables of every phase (compact active taps)
         for (int idx = tid; idx < S * 64; idx += RS_NT) {
             const int r = idx >> 6, k = (idx >> 3) & 7, j = idx & 7;
@@ -211,49 +260,63 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
             s_dq[idx] = dg;  // lib/real_equalization.py:869 uses diag(h2), not diag(h2 + h2^T)
         }
 
-        // ---- equaliser forward (lib/torch_components.py:79-96)
+        RS_STAMP(2);
+        // ---- equaliser forward (lib/torch_components.py:79-96): per 32-symbol tile Z = Kw X on the matrix cores over a
+        // 32-sample window that holds both kernels, then x = sum_i (Z_i + k1w_i) X_i
         {
-            const int nks = (l2 + 1) / 2;
-            const int jrow = lane & 31, half = lane >> 5;
-            float Areg[16];
+            const int irow = lane & 31, half = lane >> 5;
+            float Areg[16], k1w[16];
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                const int i = 2 * s + half;
-                Areg[s] = (i < l2 && jrow < l2) ? p_k2[jrow * l2 + i] + p_k2[i * l2 + jrow] : 0.f;
+                const int ia = irow - o.o2, ib = 2 * s + half - o.o2;  // lags of (row, contraction) positions
+                const bool in2 = ia >= 0 && ia < l2 && ib >= 0 && ib < l2;
+                const float ka = p_k2[in2 ? ia * l2 + ib : 0] + p_k2[in2 ? ib * l2 + ia : 0];  // index 0 is always inside s_par
+                Areg[s] = in2 ? ka : 0.f;
+                const int row = (s & 3) + 8 * (s >> 2) + 4 * half;
+                const int j1 = o.o1 - row;
+                const bool in1 = j1 >= 0 && j1 < l1;
+                const float kb = p_k1[in1 ? j1 : 0];
+                k1w[s] = in1 ? kb : 0.f;
             }
+            const int g_lo = l2 > 0 ? o.o2 / 8 : 4, g_hi = l2 > 0 ? (o.o2 + l2 - 1) / 8 : -1;  // groups of 4 contraction steps
             const int ntile = (B + 31) / 32;
             for (int tile = wv; tile < ntile; tile += RS_NW) {
-                const int b = tile * 32 + jrow;
-                const int base = RS_HL + b * S + l.p2;
-                float part = 0.f;
-                if (l2 > 0) {
-                    rs_f16 acc;
+                const int b = tile * 32 + irow;
+                const int base = RS_HL + b * S + o.c0;
+                float xb[16], xr[16];
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-#pragma unroll
-                    for (int s = 0; s < 16; ++s)
-                        if (s < nks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Areg[s], s_y[base - (2 * s + half)], acc, 0, 0, 0);
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const int j = (q & 3) + 8 * (q >> 2) + 4 * half;
-                        part = fmaf(acc[q], s_y[base - j], part);
-                    }
+                for (int s = 0; s < 16; ++s) {
+                    xb[s] = s_y[base - (2 * s + half)];
+                    xr[s] = s_y[base - ((s & 3) + 8 * (s >> 2) + 4 * half)];
                 }
-                const int b1 = RS_HL + b * S - l.pad1;
-                for (int j = half; j < l1; j += 2) part = fmaf(p_k1[j], s_y[b1 + j], part);
+                rs_f16 acc;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (g >= g_lo && g <= g_hi) {
+#pragma unroll
+                        for (int s = 4 * g; s < 4 * g + 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Areg[s], xb[s], acc, 0, 0, 0);
+                    }
+                float part = 0.f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) part = fmaf(acc[q] + k1w[q], xr[q], part);
                 part += __shfl_xor(part, 32, 64);
                 if (half == 0 && b < B) s_x[b] = part;
             }
         }
         __syncthreads();
 
+        RS_STAMP(3);
         // ---- soft demapper, moments, KL (lib/real_equalization.py:816-823, 851-866, 915-918)
         {
             double kl = 0.0;
+            double inv_den[MAX_C];
+            posterior_temperatures<CB>(p_sc, C, nv, inv_den);
             for (int b = tid; b < B; b += RS_NT) {
                 const float x = s_x[b];
                 Posterior p;
-                posterior<CB>(x, levels, p_sc, C, nv, p);
+                posterior<CB>(x, levels, inv_den, C, p);
                 float* mo = s_mom + 8 + b;
                 mo[0] = p.mu; mo[MP] = p.var; mo[2 * MP] = p.kap; mo[3 * MP] = p.gam;
                 float klb = 0.f;
@@ -266,6 +329,7 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
             KL = rs_block_sum(kl, s_dbl, tid);  // its barriers also publish the moments
         }
 
+        RS_STAMP(4);
         // ---- lagged products c_d(m) = v(m) v(m + d): totals over the batch
         {
             float c[8];
@@ -296,6 +360,7 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
             s_P[idx] = (float)(tot - edge);
         }
 
+        RS_STAMP(5);
         // ---- ELBO expectations, one window per lane (lib/real_equalization.py:868-913 in window form)
         double Eacc = 0.0;
         for (int r = 0; r < S; ++r) {
@@ -314,11 +379,22 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
                 const bool valid = (t < s1) && nn >= 0 && nn < W;
                 const bool own = valid && t >= s0;
                 const float vl = valid ? 1.f : 0.f;
-                const float yv = valid ? s_y[RS_HL + l.pre + nn] : 0.f;
+                const float yraw = s_y[RS_HL + l.pre + (valid ? nn : 0)];
+                const float yv = valid ? yraw : 0.f;
                 const float* mb = s_mom + 8 + t;
                 float mu[8], vv[8], kp[8], gm[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { mu[k] = mb[k]; vv[k] = mb[MP + k]; kp[k] = mb[2 * MP + k]; gm[k] = mb[3 * MP + k]; }
+                float h1r[8], dr[8], dqr[8];
+                {
+                    const float4* t1 = reinterpret_cast<const float4*>(s_h1c + r * 8);
+                    const float4* t2 = reinterpret_cast<const float4*>(s_d + r * 8);
+                    const float4* t3 = reinterpret_cast<const float4*>(s_dq + r * 8);
+                    const float4 a0 = t1[0], a1 = t1[1], b0 = t2[0], b1 = t2[1], c0 = t3[0], c1 = t3[1];
+                    h1r[0] = a0.x; h1r[1] = a0.y; h1r[2] = a0.z; h1r[3] = a0.w; h1r[4] = a1.x; h1r[5] = a1.y; h1r[6] = a1.z; h1r[7] = a1.w;
+                    dr[0] = b0.x; dr[1] = b0.y; dr[2] = b0.z; dr[3] = b0.w; dr[4] = b1.x; dr[5] = b1.y; dr[6] = b1.z; dr[7] = b1.w;
+                    dqr[0] = c0.x; dqr[1] = c0.y; dqr[2] = c0.z; dqr[3] = c0.w; dqr[4] = c1.x; dqr[5] = c1.y; dqr[6] = c1.z; dqr[7] = c1.w;
+                }
                 float z[8], tt[8], wq[8];
                 float pa = 0.f, pq = 0.f, ps = 0.f, psq = 0.f, pvs = 0.f;
 #pragma unroll
@@ -330,7 +406,7 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
                     float tk = g0.x * vv[0];
                     tk = fmaf(g0.y, vv[1], tk); tk = fmaf(g0.z, vv[2], tk); tk = fmaf(g0.w, vv[3], tk);
                     tk = fmaf(g1.x, vv[4], tk); tk = fmaf(g1.y, vv[5], tk); tk = fmaf(g1.z, vv[6], tk); tk = fmaf(g1.w, vv[7], tk);
-                    const float h1k = s_h1c[r * 8 + k], dk = s_d[r * 8 + k], dqk = s_dq[r * 8 + k];
+                    const float h1k = h1r[k], dk = dr[k], dqk = dqr[k];
                     const float zk = fmaf(2.f, u, h1k);
                     pa = fmaf(h1k, mu[k], pa);
                     pq = fmaf(mu[k], u, pq);
@@ -351,7 +427,7 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
                     float hw = h0.x * wq[0];
                     hw = fmaf(h0.y, wq[1], hw); hw = fmaf(h0.z, wq[2], hw); hw = fmaf(h0.w, wq[3], hw);
                     hw = fmaf(h1v.x, wq[4], hw); hw = fmaf(h1v.y, wq[5], hw); hw = fmaf(h1v.z, wq[6], hw); hw = fmaf(h1v.w, wq[7], hw);
-                    const float dk = s_d[r * 8 + k], dqk = s_dq[r * 8 + k];
+                    const float dk = dr[k], dqk = dqr[k];
                     s_D[(0 * 8 + k) * RS_NT + tid] = vl * (2.f * e * z[k] + 2.f * hw);
                     s_D[(1 * 8 + k) * RS_NT + tid] = vl * (2.f * A * dk - 2.f * yv * dqk + z[k] * z[k] + 4.f * tt[k]);
                     s_D[(2 * 8 + k) * RS_NT + tid] = vl * (2.f * dk * z[k]);
@@ -368,13 +444,17 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
                 // gather: symbol m = s0 + tid collects window t = m - kk at compact tap kk
                 if (tid < o.TS && s0 + tid < s1) {
                     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-                    for (int kk = 0; kk < LE; ++kk) {
-                        const int slot = tid + kmax - kk;
-                        a0 += s_D[(0 * 8 + kk) * RS_NT + slot];
-                        a1 += s_D[(1 * 8 + kk) * RS_NT + slot];
-                        a2 += s_D[(2 * 8 + kk) * RS_NT + slot];
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) {
+                        const bool act = kk < LE;
+                        const int slot = act ? tid + kmax - kk : 0;
+                        const float d0 = s_D[(0 * 8 + kk) * RS_NT + slot], d1 = s_D[(1 * 8 + kk) * RS_NT + slot];
+                        const float d2 = s_D[(2 * 8 + kk) * RS_NT + slot], vs = s_vl[slot];
                         const float dk = s_d[r * 8 + kk];
-                        a3 = fmaf(s_vl[slot], dk * dk, a3);
+                        a0 += act ? d0 : 0.f;
+                        a1 += act ? d1 : 0.f;
+                        a2 += act ? d2 : 0.f;
+                        a3 = fmaf(act ? vs : 0.f, dk * dk, a3);
                     }
                     float* gp = s_gm + s0 + tid;
                     if (r == 0) { gp[0] = a0; gp[GP] = a1; gp[2 * GP] = a2; gp[3 * GP] = a3; }
@@ -382,33 +462,48 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
                 }
                 __syncthreads();
             }
-            const float gt = rs_wave_reduce_transposed<64>(G, lane);
-            s_gred[(wv * S + r) * RS_GREC + rs_transposed_index<64>(lane)] = gt;
-            const float ft = rs_wave_reduce_transposed<32>(F, lane);
-            if (lane < 32) s_gred[(wv * S + r) * RS_GREC + 64 + rs_transposed_index<32>(lane)] = ft;
+            // cross-lane sums: two butterfly steps in registers, then [slot][element] through LDS (pitch 97)
+            rs_quad_fold<64>(G, lane);
+            rs_quad_fold<32>(F, lane);
+            {
+                float* R = s_D + (wv * 16 + (lane >> 2)) * 97;
+                const int eg = (lane & 1) * 32 + ((lane >> 1) & 1) * 16, ef = 64 + (lane & 1) * 16 + ((lane >> 1) & 1) * 8;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) R[eg + i] = G[i];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) R[ef + i] = F[i];
+            }
+            __syncthreads();
+            {
+                const int e = tid >> 1, part = tid & 1;
+                float sacc = 0.f;
+                if (e < RS_GREC)
+                    for (int slot = part * (RS_NW * 8); slot < (part + 1) * (RS_NW * 8); ++slot) sacc += s_D[slot * 97 + e];
+                sacc += rs_quad_xor1(sacc);
+                if (e < RS_GREC && part == 0) s_gtot[r * RS_GREC + e] = sacc;
+            }
+            __syncthreads();
         }
+        RS_STAMP(6);
         E = rs_block_sum(Eacc, s_dbl, tid);
         loss = KL + (double)W * log(E);
         lamd = (double)W / E;
         const float lam = (float)lamd;
 
-        // ---- totals of the per-wave records (the barriers of the block sum published them)
-        for (int idx = tid; idx < S * RS_GREC; idx += RS_NT) {
-            const int r = idx / RS_GREC, e = idx - r * RS_GREC;
-            double s = 0.0;
-            for (int w = 0; w < RS_NW; ++w) s += (double)s_gred[(w * S + r) * RS_GREC + e];
-            s_gtot[idx] = (float)s;
-        }
-
+        RS_STAMP(7);
         // ---- per-symbol backward: moments -> posterior -> equaliser output, noise scaling (softmax backward in double)
         {
             float gs[MAX_C];
 #pragma unroll
             for (int k = 0; k < CB; ++k) gs[k] = 0.f;
+            double inv_den[MAX_C], inv_den_sc[MAX_C];
+            posterior_temperatures<CB>(p_sc, C, nv, inv_den);
+#pragma unroll
+            for (int k = 0; k < CB; ++k) inv_den_sc[k] = k < C ? inv_den[k] / (double)p_sc[k] : 0.0;
             for (int b = tid; b < B; b += RS_NT) {
                 const float x = s_x[b];
                 Posterior p;
-                posterior<CB>(x, levels, p_sc, C, nv, p);
+                posterior<CB>(x, levels, inv_den, C, p);
                 const float* g = s_gm + b;
                 const float gmu = g[0], gv = g[GP], gk = g[2 * GP], gg = g[3 * GP];
                 const bool in_kl = b >= l.kl_lo && b < l.kl_hi;
@@ -434,9 +529,8 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
                     if (k < C) {
                         const double dz = (double)p.q[k] * (dq[k] - qdq);
                         const double df = (double)x - (double)levels[k];
-                        const double den = (double)nv * (double)p_sc[k];
-                        gxd += dz * (-2.0 * df / den);
-                        gs[k] += (float)(dz * df * df / (den * (double)p_sc[k]));
+                        gxd += dz * (-2.0 * df * inv_den[k]);
+                        gs[k] += (float)(dz * df * df * inv_den_sc[k]);
                     }
                 s_gx[b] = (float)gxd;
             }
@@ -450,6 +544,7 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
         }
         __syncthreads();
 
+        RS_STAMP(8);
         // ---- channel gradients: chain from compact per-phase totals to h1, h2
         for (int idx = tid; idx < n0 + n1; idx += RS_NT) {
             auto compact = [&](int t, int& r, int& k) {
@@ -484,51 +579,58 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
             s_grad[n0 + n1 + n2 + n3 + tid] = s;
         }
 
-        // ---- equaliser backward: first-order kernel, then X^T diag(g) X on the matrix cores
+        RS_STAMP(9);
+        // ---- equaliser backward: X^T diag(g) X over the 32-sample window on the matrix cores, symbols as the contraction
+        // index; the first-order gradient is the row sum of the same A operand
         {
-            const int ngrp = RS_NT / l1;
-            const int j = tid % l1, grp = tid / l1;
-            float acc = 0.f;
-            if (grp < ngrp)
-                for (int b = grp; b < B; b += ngrp) acc = fmaf(s_gx[b], s_y[RS_HL + b * S - l.pad1 + j], acc);
-            // the ELBO stage is over: its per-window image is free for the partial sums
-            if (grp < ngrp) s_D[RS_NW * 1024 + grp * l1 + j] = acc;
-        }
-        if (l2 > 0) {
             rs_f16 acc;
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+            float asum = 0.f;
             const int i = lane & 31, half = lane >> 5;
             const int npair = (B + 1) / 2;
-            for (int pq = wv; pq < npair; pq += RS_NW) {
-                const int b = 2 * pq + half;
-                const float xv = s_y[RS_HL + b * S + l.p2 - i];
-                const float gv = s_gx[b];  // zero beyond the batch
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gv * xv, xv, acc, 0, 0, 0);
+            const float* yw = s_y + RS_HL + o.c0 - i;
+            for (int pq = wv; pq < npair; pq += 4 * RS_NW) {
+                float xv[4], av[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    // pairs past the end read the zero padding of both arrays (up to 8 RS_NW symbols beyond the batch)
+                    const int b = 2 * (pq + u * RS_NW) + half;
+                    xv[u] = yw[b * S];
+                    av[u] = s_gx[b] * xv[u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    asum += av[u];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], xv[u], acc, 0, 0, 0);
+                }
             }
+            // the ELBO stage is over: its per-window image is free for the cross-wave sums
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int row = (q & 3) + 8 * (q >> 2) + 4 * half;
                 s_D[wv * 1024 + row * 32 + i] = acc[q];
             }
+            asum += __shfl_xor(asum, 32, 64);
+            if (half == 0) s_D[RS_NW * 1024 + wv * 32 + i] = asum;
         }
         __syncthreads();
         {
-            const int ngrp = RS_NT / l1;
             if (tid < l1) {
-                float s = 0.f;
-                for (int g = 0; g < ngrp; ++g) s += s_D[RS_NW * 1024 + g * l1 + tid];
-                s_grad[n0 + n1 + tid] = s;
+                float sacc = 0.f;
+                for (int w = 0; w < RS_NW; ++w) sacc += s_D[RS_NW * 1024 + w * 32 + o.o1 - tid];
+                s_grad[n0 + n1 + tid] = sacc;
             }
             for (int e = tid; e < n3; e += RS_NT) {
-                const int i = e / l2, j = e - i * l2;
-                float s = 0.f;
-                for (int w = 0; w < RS_NW; ++w) s += s_D[w * 1024 + i * 32 + j] + s_D[w * 1024 + j * 32 + i];
-                s_grad[n0 + n1 + n2 + e] = s;
+                const int ia = e / l2 + o.o2, ib = e % l2 + o.o2;
+                float sacc = 0.f;
+                for (int w = 0; w < RS_NW; ++w) sacc += s_D[w * 1024 + ia * 32 + ib] + s_D[w * 1024 + ib * 32 + ia];
+                s_grad[n0 + n1 + n2 + e] = sacc;
             }
         }
         __syncthreads();
 
+        RS_STAMP(10);
         // ---- Adam with AMSGrad (torch.optim.Adam single-tensor arithmetic), noise variance, loss
         {
             const float step_size = a.step_size[n], bc2_sqrt = a.bc2_sqrt[n];
@@ -549,6 +651,7 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
             if (tid == 0 && a.loss_curve) a.loss_curve[(int64_t)model * a.n_batches + n] = (float)loss;
         }
         __syncthreads();
+        RS_STAMP(11);
     }
 
     // ---- state back to global memory

@@ -399,12 +399,17 @@ __device__ __forceinline__ void d_demap_moments(const GridCtx gc, Lay l, const f
     const float nv = noise_var[0];
     float* __restrict__ mom = ws + l.o_mom;
     double kl = 0.0;
+    double inv_den[2][MAX_C];
+    posterior_temperatures<CB>(scaling, l.C, nv, inv_den[0]);
+    posterior_temperatures<CB>(scaling + (l.ns - 1) * l.C, l.C, nv, inv_den[1]);
     for (int64_t i = (int64_t)gc.bid * NT + threadIdx.x; i < l.sym_cnt; i += (int64_t)gc.nb * NT) {
         const int64_t b = l.sym_lo + i;
         const bool in_kl = b >= l.kl_lo && b < l.kl_hi && b >= l.own_lo && b < l.own_lo + l.own_cnt;
-        for (int c = 0; c < l.ns; ++c) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if (c >= l.ns) break;
             Posterior p;
-            posterior<CB>(xhat[(int64_t)c * l.sym_cnt + i], levels + c * l.C, scaling + c * l.C, l.C, nv, p);
+            posterior<CB>(xhat[(int64_t)c * l.sym_cnt + i], levels + c * l.C, inv_den[c], l.C, p);
             float* m = mom + (int64_t)c * 4 * l.sym_cnt + i;
             m[0] = p.mu; m[l.sym_cnt] = p.var; m[2 * l.sym_cnt] = p.kap; m[3 * l.sym_cnt] = p.gam;
             float klb = 0.f;
@@ -466,6 +471,9 @@ __device__ __forceinline__ void d_sym_bwd(const GridCtx gc, Lay l, const float* 
     for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int k = 0; k < CB; ++k) gs[c][k] = 0.f;
+    double inv_den[2][MAX_C];
+    posterior_temperatures<CB>(scaling, l.C, nv, inv_den[0]);
+    posterior_temperatures<CB>(scaling + (l.ns - 1) * l.C, l.C, nv, inv_den[1]);
     for (int64_t i = (int64_t)gc.bid * NT + threadIdx.x; i < l.sym_cnt; i += (int64_t)gc.nb * NT) {
         const int64_t b = l.sym_lo + i;
         const bool own = b >= l.own_lo && b < l.own_lo + l.own_cnt;
@@ -479,7 +487,7 @@ __device__ __forceinline__ void d_sym_bwd(const GridCtx gc, Lay l, const float* 
                     const float* lv = levels + c * l.C;
                     const float* sc = scaling + c * l.C;
                     Posterior p;
-                    posterior<CB>(x, lv, sc, l.C, nv, p);
+                    posterior<CB>(x, lv, inv_den[c], l.C, p);
                     const float* g = gmom + (int64_t)c * 4 * l.sym_cnt + i;
                     const float gmu = g[0], gv = g[l.sym_cnt], gk = g[2 * l.sym_cnt], gg = g[3 * l.sym_cnt];
                     // Softmax backward cancels dq against its posterior mean; for peaked posteriors the
@@ -507,9 +515,8 @@ __device__ __forceinline__ void d_sym_bwd(const GridCtx gc, Lay l, const float* 
                         if (k < l.C) {
                             const double dz = (double)p.q[k] * (dq[k] - qdq);
                             const double df = (double)x - (double)lv[k];
-                            const double den = (double)nv * (double)sc[k];
-                            gxd += dz * (-2.0 * df / den);
-                            gs[c][k] += (float)(dz * df * df / (den * (double)sc[k]));
+                            gxd += dz * (-2.0 * df * inv_den[c][k]);
+                            gs[c][k] += (float)(dz * df * df * inv_den[c][k] / (double)sc[k]);
                         }
                     gx = (float)gxd;
                 }

@@ -14,9 +14,17 @@ struct Posterior {
     float mu, var, kap, gam;
 };
 
+// inv_den[i] = 1 / (noise variance * scaling[i]) in double, computed once per thread (a double division costs
+// more than the rest of the posterior together)
 template <int CB>
-__device__ __forceinline__ void posterior(float x, const float* __restrict__ lv, const float* __restrict__ sc, int C,
-                                          float nv, Posterior& p) {
+__device__ __forceinline__ void posterior_temperatures(const float* __restrict__ sc, int C, float nv, double (&inv_den)[MAX_C]) {
+#pragma unroll
+    for (int i = 0; i < CB; ++i) inv_den[i] = i < C ? 1.0 / ((double)nv * (double)sc[i]) : 0.0;
+}
+
+template <int CB>
+__device__ __forceinline__ void posterior(float x, const float* __restrict__ lv, const double (&inv_den)[MAX_C], int C,
+                                          Posterior& p) {
     // Logits reach |z| ~ 1e2..1e3 for small noise variance; rounding them to fp32 before the max is
     // subtracted would put ~|z| * 6e-8 of absolute error into the exponent, i.e. that much RELATIVE
     // error into q.  The difference z - max is therefore formed in double and only then rounded.
@@ -26,7 +34,7 @@ __device__ __forceinline__ void posterior(float x, const float* __restrict__ lv,
     for (int i = 0; i < CB; ++i)
         if (i < C) {
             const double d = (double)x - (double)lv[i];
-            zd[i] = -(d * d) / ((double)nv * (double)sc[i]);
+            zd[i] = -(d * d) * inv_den[i];
             mx = fmax(mx, zd[i]);
         }
     float sum = 0.f;
