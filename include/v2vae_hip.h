@@ -193,13 +193,22 @@ int v2vae_adam_schedule(int64_t step0, int64_t n, const float* lr, float beta1, 
                         float* bc2_sqrt);
 
 /* The whole mini-batch loop of GenericTorchBlindEqualizer.fit (lib/real_equalization.py:482-502) for n_models
- * independent models in ONE launch: one workgroup per model runs n_batches sequential training steps
- * (same stages, same arithmetic and summation order as v2vae_train_step on the generic kernels), so the
+ * independent models in ONE launch: one workgroup per model runs n_batches sequential training steps, so the
  * launch-bound small-batch configuration costs one launch per fit instead of ~17 per batch, and a sweep of
  * models (channels / SNR points / seeds) fills the GPU.  `p` describes ONE batch as a whole sequence
- * (n_glob = y_len = B*sps, y_lo = sym_lo = own_lo = 0, sym_cnt = own_cnt = B).  V2VAE_ESIZE if the shape
- * needs more than one accumulator tile per thread in the ELBO stage (then use v2vae_train_step). */
+ * (n_glob = y_len = B*sps, y_lo = sym_lo = own_lo = 0, sym_cnt = own_cnt = B).
+ * Two kernels (v2vae_fit_persistent_kind tells which): the on-chip kernel keeps batch, moments, tables, parameters
+ * and optimiser state in LDS / registers (same mathematics as v2vae_train_step, its own summation order: results
+ * agree to fp32 rounding); the stage-by-stage kernel runs the generic stage code of v2vae_train_step in the same
+ * order (bit-identical results) out of the workspace.  xhat, gxhat and ws are only touched by the latter.
+ * V2VAE_ESIZE if neither covers the shape (then use v2vae_train_step). */
 int v2vae_fit_persistent(const v2vae_problem* p, const v2vae_fit_args* a, void* stream);
+
+/* Which kernel v2vae_fit_persistent would run for this one-batch problem: 2 = the on-chip kernel (real model,
+ * <= 8 active channel taps per phase, both equaliser kernels inside one 32-sample window, batch and parameters
+ * fit LDS/registers): fastest route for small batches; 1 = the stage-by-stage persistent kernel (meant for sweeps of
+ * many models); negative = status code (shape not supported by either). */
+int v2vae_fit_persistent_kind(const v2vae_problem* p);
 
 /* Read-only views into the workspace for tests and tooling: float offsets (in floats from the
  * workspace base) of the per-symbol moments [ns][4][sym_cnt] and of dE/d(moments), same shape. */

@@ -190,3 +190,35 @@ def test_persistent_rejects_bad_arguments():
                adam_v=z(2, pf.pack), adam_vmax=z(2, pf.pack), noise_var=z(2), lrs=[1e-3] * 3)  # sequence too short
     with pytest.raises(V2VAEError):
         PersistentFit(ns=1, sps=2, l1=11, pad1=5, l2=8, L=9, C_levels=4, batch_symbols=100, n_models=1, device=dev)  # even lags
+
+
+def test_sweep_class_equals_individual_models():
+    """SecondVolterraV2VAESweep (one launch for all models) == one drop-in SecondVolterraV2VAE per model."""
+    from volterra_vae_amd.real_equalization import SecondVolterraV2VAE
+    from volterra_vae_amd.sweep import SecondVolterraV2VAESweep
+    from volterra_vae_amd.synth import nonlinear_isi, pam_constellation
+    S, B, L, l1, l2, nb, M = 2, 250, 15, 25, 25, 20, 4
+    const = pam_constellation(4)
+    rng = np.random.default_rng(9)
+    snrs = (10.0, 14.0, 18.0, 22.0)
+    rxs = np.stack([nonlinear_isi(nb * B, const, S, snr, rng)[0] for snr in snrs])
+    nv0 = [10 ** (-snr / 10) for snr in snrs]
+    dev = torch.device("cuda")
+    sweep = SecondVolterraV2VAESweep(M, L, l1, l2, 5e-3, const, S, B, noise_variance=nv0, torch_device=dev)
+    assert sweep._fit.on_chip
+    y_eq, curves = sweep.fit(rxs)
+    assert y_eq.shape == (M, nb * B) and curves.shape == (M, nb)
+    dec = sweep.decide(rxs)
+    for m in range(M):
+        one = SecondVolterraV2VAE(channel_memory=L, learning_rate=5e-3, constellation=const, samples_per_symbol=S, batch_size=B,
+                                  noise_variance=nv0[m], torch_device=dev, equaliser_n_lags1=l1, equaliser_n_lags2=l2)
+        one.initialize_optimizer()
+        ye, lc = one.fit(rxs[m])
+        assert np.array_equal(ye, y_eq[m]) and np.array_equal(lc, curves[m])
+        assert torch.equal(one._pack, sweep.params[m])
+        assert torch.equal(one._noise_var[0], sweep.noise_variance[m])
+        q = one.estimate_symbol_probs(rxs[m])
+        assert np.array_equal(q.argmax(axis=0), dec[m])
+    # second call continues optimiser state and schedule position
+    y2, c2 = sweep.fit(rxs)
+    assert np.isfinite(c2).all() and sweep.step_count == 2 * nb

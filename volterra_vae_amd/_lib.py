@@ -74,6 +74,7 @@ EXPORTS = {
     "v2vae_train_step": (C.c_int, [C.POINTER(Problem), C.POINTER(TrainArgs), C.c_void_p]),
     "v2vae_adam_schedule": (C.c_int, [C.c_int64, C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "v2vae_fit_persistent": (C.c_int, [C.POINTER(Problem), C.POINTER(FitArgs), C.c_void_p]),
+    "v2vae_fit_persistent_kind": (C.c_int, [C.POINTER(Problem)]),
     "v2vae_ws_offset_moments": (C.c_int64, [C.POINTER(Problem)]),
     "v2vae_ws_offset_gmoments": (C.c_int64, [C.POINTER(Problem)]),
 }

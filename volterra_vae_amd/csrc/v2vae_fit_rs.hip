@@ -674,6 +674,11 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
     }
 }
 
+int fit_rs_applicable(const Lay& l, int64_t pack) {
+    RsOff o;
+    return rs_plan(l, pack, &o);
+}
+
 // Launches the on-chip fit kernel if the shape fits it; returns 1 if launched, 0 if not applicable, < 0 on error.
 int launch_fit_rs(const Lay& l, const v2vae_fit_args* a, const int64_t n[5], hipStream_t st) {
     RsOff o;

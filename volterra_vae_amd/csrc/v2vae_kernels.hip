@@ -1605,6 +1605,20 @@ int v2vae_adam_schedule(int64_t step0, int64_t n, const float* lr, float beta1, 
     return V2VAE_OK;
 }
 
+int v2vae_fit_persistent_kind(const v2vae_problem* p) {
+    if (!p) return V2VAE_EINVAL;
+    Lay l;
+    int rc = make_layout(p, &l);
+    if (rc) return rc;
+    if (l.y_lo != 0 || l.sym_lo != 0 || l.own_lo != 0 || l.y_len != l.n_glob || l.sym_cnt != l.b_glob || l.own_cnt != l.b_glob)
+        return V2VAE_EINVAL;
+    int64_t n[5];
+    v2vae_pack_sizes(p, n);
+    if (fit_rs_applicable(l, n[0] + n[1] + n[2] + n[3] + n[4])) return 2;
+    if (l.maxi_elbo != 1 || l.maxi_eq > 2) return V2VAE_ESIZE;
+    return 1;
+}
+
 int v2vae_fit_persistent(const v2vae_problem* p, const v2vae_fit_args* a, void* stream) {
     if (!p || !a) return V2VAE_EINVAL;
     Lay l;

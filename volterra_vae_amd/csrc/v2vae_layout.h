@@ -85,5 +85,6 @@ void launch_finish_equaliser_cx(const Lay& l, float* ws, float* g_k1, float* g_k
 
 // v2vae_fit_rs.hip: whole fit loop on chip for small real shapes; 1 = launched, 0 = shape not covered, < 0 = error
 int launch_fit_rs(const Lay& l, const v2vae_fit_args* a, const int64_t n[5], hipStream_t st);
+int fit_rs_applicable(const Lay& l, int64_t pack);
 
 }  // namespace v2vae

@@ -150,7 +150,10 @@ class PersistentFit:
         p.n_glob = p.y_len = batch_symbols * sps
         p.y_lo = p.sym_lo = p.own_lo = 0
         p.sym_cnt = p.own_cnt = batch_symbols
-        check(lib.v2vae_check_problem(C.byref(p)), "v2vae_check_problem")
+        kind = lib.v2vae_fit_persistent_kind(C.byref(p))
+        if kind < 0:
+            check(kind, "v2vae_fit_persistent_kind")
+        self.on_chip = kind == 2  # the whole step stays in LDS/registers (small real shapes)
         self.p, self.device, self.n_models, self.B = p, device, n_models, batch_symbols
         self.sizes = _lib.pack_sizes(p)
         self.pack = sum(self.sizes)

@@ -288,11 +288,11 @@ class VAESecondVolterraForward(GenericTorchBlindProbabilisticEqualizer):
         if self.learnable_noise_scaling:
             self.noise_scaling.grad = None
 
-    # True: fit() runs the whole mini-batch loop as ONE persistent kernel launch (one workgroup) when the shape allows;
-    # False: one fused kernel sequence per batch.  Bitwise identical results.  A single model on a single workgroup
-    # leaves the other 255 compute units idle and measures slower than the per-batch sequence (456 vs 172 us per
-    # 500-symbol step), so the default is False; sweeps of many models use the persistent kernel (ops.PersistentFit).
-    persistent_fit = False
+    # None (default): fit() runs the whole mini-batch loop as ONE launch when the on-chip kernel covers the shape (small
+    # real shapes: 42 us per 500-symbol step instead of 171 us), else one fused kernel sequence per batch.
+    # True: always one launch (the stage-by-stage persistent kernel for shapes the on-chip one does not cover; it is
+    # bitwise equal to the per-batch sequence but slower for a single model).  False: always per batch.
+    persistent_fit = None
 
     def _persistent(self, B):
         key = ("persistent", B)
@@ -321,7 +321,11 @@ class VAESecondVolterraForward(GenericTorchBlindProbabilisticEqualizer):
         opt = self.optimizer
         opt._opt_called = True  # the fused step below is the optimizer step
         levels, prior = self._levels2d(), self.constellation_prior.view(1, -1).contiguous()
-        pf = self._persistent(B) if (self.persistent_fit and n_batches and B <= self.PERSISTENT_MAX_BATCH) else None
+        pf = None
+        if self.persistent_fit is not False and n_batches and B <= self.PERSISTENT_MAX_BATCH:
+            pf = self._persistent(B)
+            if pf is not None and self.persistent_fit is None and not pf.on_chip:
+                pf = None
         if pf is not None:
             lrs, shown = [], []
             for n in range(n_batches):
