@@ -63,6 +63,86 @@ def cpu_baseline(L, S, l1, l2, order, budget_s=12.0):
             "sample": f"{n} train steps of one {B}-symbol batch (same model shape, fp32, torch CPU oracle, window form)"}
 
 
+def sweep_main(args):
+    """BASELINE.json configs[4]: 1024 independent channel/SNR points, real PAM-4, L=15 (S=2, l1=l2=25 and 500-symbol
+    batches as in the reference's default script), models split over the ranks, no collective.  A step = one
+    mini-batch training step of every model; the timed region is ONE launch of --steps batches per rank."""
+    import torch
+    import torch.distributed as dist
+    from volterra_vae_amd.sweep import SecondVolterraV2VAESweep, shard_models
+    from volterra_vae_amd.synth import nonlinear_isi, pam_constellation
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    n_total, L, S, l1, l2, B, C = 1024, 15, 2, 25, 25, 500, 4
+    lo, hi = shard_models(rank, world, n_total)
+    M = hi - lo
+    const = pam_constellation(C)
+    nbt = args.warmup + args.steps
+    # 16 distinct synthetic sequences (SNR 10..25 dB) shared round-robin by the models of this rank
+    snrs = np.linspace(10.0, 25.0, 16)
+    base = np.stack([nonlinear_isi(nbt * B, const, S, snr, np.random.default_rng(100 + i))[0] for i, snr in enumerate(snrs)])
+    idx = (np.arange(lo, hi) % 16)
+    sweep = SecondVolterraV2VAESweep(M, L, l1, l2, 5e-3, const, S, B, noise_variance=10 ** (-snrs[idx] / 10), torch_device=dev,
+                                     lr_schedule=None)
+    y = torch.from_numpy(base[idx].astype(np.float32)).view(M, 1, -1).to(dev).contiguous()
+    lv, prior = sweep.constellation.view(1, -1), sweep.constellation_prior.view(1, -1)
+    kw = dict(levels=lv, prior=prior, params=sweep.params, grads=sweep._grads, adam_m=sweep._m, adam_v=sweep._v,
+              adam_vmax=sweep._vmax, noise_var=sweep.noise_variance)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    if args.warmup:
+        sweep._fit.run(y=y[:, :, :args.warmup * B * S].contiguous(), lrs=[5e-3] * args.warmup, step0=0, **kw)
+    ys = y[:, :, args.warmup * B * S:].contiguous()
+    lc = torch.zeros((M, args.steps), dtype=torch.float32, device=dev)
+    fence()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    sweep._fit.run(y=ys, lrs=[5e-3] * args.steps, step0=args.warmup, loss_curve=lc, **kw)
+    e1.record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = e0.elapsed_time(e1)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    if not bool(torch.isfinite(lc).all()):
+        raise SystemExit("non-finite loss in the sweep")
+    if rank == 0:
+        fl = algorithmic_flops_per_symbol(L, S, l1, l2, False)
+        flops_launch = sum(fl.values()) * M * B * args.steps
+        achieved = flops_launch / (kernel_ms * 1e-3) / 1e12
+        out = {
+            "metric": "V2VAE train-step symbols/sec (fwd+bwd) at 1/2/4/8 MI355X; % of HBM/MFMA roofline",
+            "value": n_total * B * args.steps / elapsed, "unit": "symbols/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"batched sweep: {n_total} independent real PAM-4 V2VAE models, L=15, l1=l2=25, sps=2, "
+                                   f"{B}-symbol mini-batches, Adam-AMSGrad, one persistent launch per rank",
+                       "models_per_gpu": M, "parallelism": f"models split over {world} ranks, no collective"},
+            "roofline": {"bound": "mfma", "kernel": "k_fit_rs", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                         "algorithmic_flops_per_symbol": sum(fl.values()), "kernel_ms": kernel_ms},
+            "final_loss_mean": float(lc[:, -1].mean()),
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -70,7 +150,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2-symbols", type=int, default=22, help="symbols per GPU = 2^this")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["train_step", "sweep"], default="train_step",
+                    help="train_step: the headline configuration (default); sweep: 1024 independent real PAM-4 models, L=15")
     args = ap.parse_args()
+    if args.workload == "sweep":
+        return sweep_main(args)
 
     import torch
     import torch.distributed as dist
