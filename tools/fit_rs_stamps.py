@@ -39,10 +39,16 @@ nv = torch.full((1,), 10 ** -1.6, dtype=torch.float32, device=dev)
 for _ in range(2):
     pf.run(y=y, levels=lv, prior=prior, params=prm, grads=st[0], adam_m=st[1], adam_v=st[2], adam_vmax=st[3], noise_var=nv, lrs=[5e-3] * nb)
 torch.cuda.synchronize()
-t = pf.ws[0, :24].cpu().numpy().view(np.uint64)[:12].astype(np.int64)
+raw = pf.ws[0, :44].cpu().numpy().view(np.uint64).astype(np.int64)
+t = raw[:12]
+print(f"shader-clock cycles per step: {raw[13] - raw[12]} -> {(raw[13] - raw[12]) / ((t[11] - t[0]) * 10e-3):.0f} MHz effective")
 names = ["load params+samples", "tables", "equaliser fwd", "demap+moments+KL", "lag totals + P", "ELBO windows", "E sum, totals",
          "symbol backward", "channel chain", "equaliser bwd", "Adam"]
 d = np.diff(t) * 10e-3  # 10 ns ticks -> us
 for nm, v in zip(names, d):
     print(f"{nm:24s} {v:8.2f} us")
 print(f"{'step':24s} {d.sum():8.2f} us")
+
+sub = raw[14:21]
+for nm, v in zip(["pass 1 (u, tt, scalars)", "pass 2 (Hw, D stores, F)", "quad outer products", "barrier", "gather + barrier", "fold + LDS sum"], np.diff(sub) * 10e-3):
+    print(f"  phase 0: {nm:26s} {v:6.2f} us")

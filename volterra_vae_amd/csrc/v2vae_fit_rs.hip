@@ -25,9 +25,12 @@
 namespace v2vae {
 
 constexpr int RS_NT = 256;          // threads per workgroup
+constexpr int RS_SLOTS = 512;       // window slots per chunk of the ELBO stage (each thread takes RS_SLOTS / RS_NT of them)
+constexpr int RS_PARTS = RS_NT / 128;  // threads sharing one element of the cross-lane sum
 constexpr int RS_NW = RS_NT / 64;   // waves
 constexpr int RS_HL = 32;           // zero samples kept left of the batch in LDS
 constexpr int RS_APT = 8;           // optimiser elements per thread (parameter pack <= RS_APT * RS_NT)
+constexpr int RS_YPT = 8;           // samples per thread fetched one batch ahead (batches up to RS_YPT * RS_NT samples)
 constexpr int RS_GREC = 96;         // per-wave, per-phase record: G 8x8 | f1 8 | f2 8 | f3 8 | pad 8
 
 typedef float rs_f16 __attribute__((ext_vector_type(16)));
@@ -47,7 +50,7 @@ int rs_plan(const Lay& l, int64_t pack, RsOff* o) {
     if (pack > RS_APT * RS_NT || l.b_glob > 4096 || l.n_glob > 8192) return 0;
     const int B = (int)l.b_glob, N = (int)l.n_glob;
     RsOff r{};
-    r.TS = RS_NT - l.kmax;
+    r.TS = RS_SLOTS - l.kmax;
     r.nchunks = (B + r.TS - 1) / r.TS;
     r.packp = rs_rup((int)pack, 64);
     {
@@ -62,18 +65,18 @@ int rs_plan(const Lay& l, int64_t pack, RsOff* o) {
     r.y = take(RS_HL + N + 32 * l.S + 64);
     r.x = take(rs_rup(B, 64) + 64);
     r.gx = take(rs_rup(B, 64) + 64);
-    r.MP = rs_rup(8 + (r.nchunks - 1) * r.TS + RS_NT + 8, 4);
+    r.MP = rs_rup(8 + (r.nchunks - 1) * r.TS + RS_SLOTS + 8, 4);
     r.mom = take(4 * r.MP);
     r.GP = rs_rup(B, 4);
     r.gm = take(4 * r.GP);
     {   // per-window gradient image of the ELBO stage; later the cross-lane reduction image (64 slots, pitch 97) and the
         // cross-wave image of the equaliser-gradient tiles
-        int nd = 3 * 8 * RS_NT;
-        if (nd < 64 * 97) nd = 64 * 97;
+        int nd = 3 * 8 * RS_SLOTS;
+        if (nd < RS_NW * 16 * 97) nd = RS_NW * 16 * 97;
         if (nd < RS_NW * 1024 + RS_NW * 32) nd = RS_NW * 1024 + RS_NW * 32;
         r.D = take(nd);
     }
-    r.vl = take(RS_NT);
+    r.vl = take(RS_SLOTS);
     r.H = take(l.S * 64);
     r.HH = take(l.S * 64);
     r.h1c = take(l.S * 8);
@@ -117,6 +120,34 @@ __device__ __forceinline__ float rs_quad_xor1(float v) {  // value of lane ^ 1 (
 }
 __device__ __forceinline__ float rs_quad_xor2(float v) {  // value of lane ^ 2 (DPP quad_perm [2,3,0,1])
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
+}
+
+template <int CTRL>
+__device__ __forceinline__ float rs_quad_perm(float v) {  // DPP quad_perm: 0xB1 = lane ^ 1, 0x4E = lane ^ 2, 0x1B = lane ^ 3
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+// Outer-product accumulation G += a mu^T summed over the four lanes of a quad, kept in folded form: lane q = lane & 3 owns
+// rows 2q, 2q + 1 (16 of the 64 elements), so every lane fetches from its three quad partners the two `a` values of
+// ITS rows (the sender selects them) and the partner's eight mu values, all through DPP -- 64 FMAs per lane as for a
+// private 8x8 accumulator, but 16 registers instead of 64 and no fold afterwards.
+template <int CTRL>
+__device__ __forceinline__ void rs_quad_outer(float (&G2)[2][8], const float (&ak)[8], const float (&mu)[8], int q) {
+    const int idx = CTRL == 0 ? q : (CTRL == 0xB1 ? q ^ 1 : (CTRL == 0x4E ? q ^ 2 : q ^ 3));  // receiver's q, seen from the sender
+    float r[2];
+#pragma unroll
+    for (int odd = 0; odd < 2; ++odd) {
+        const float lo = (idx & 2) ? ak[4 + odd] : ak[odd];
+        const float hi = (idx & 2) ? ak[6 + odd] : ak[2 + odd];
+        const float v = (idx & 1) ? hi : lo;
+        r[odd] = CTRL == 0 ? v : rs_quad_perm<CTRL == 0 ? 0xB1 : CTRL>(v);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float m = CTRL == 0 ? mu[j] : rs_quad_perm<CTRL == 0 ? 0xB1 : CTRL>(mu[j]);
+        G2[0][j] = fmaf(r[0], m, G2[0][j]);
+        G2[1][j] = fmaf(r[1], m, G2[1][j]);
+    }
 }
 
 // Two transposing butterfly steps inside each quad of lanes: afterwards x[0 .. N/4) hold, summed over the lane's quad,
@@ -174,6 +205,7 @@ __device__ __forceinline__ int rs_tap(const Lay& l, int r, int k) {
 #else
 #define RS_STAMP(i) do { } while (0)
 #endif
+#define RS_SUB(i, cond) do { if (cond) RS_STAMP(i); } while (0)
 
 template <int CB>
 __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args a, int n0, int n1, int n2, int n3, int n4) {
@@ -229,17 +261,34 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
     const float* levels = a.levels;
     const float* prior = a.prior;
     __syncthreads();
+    const bool y_ahead = N <= RS_YPT * RS_NT;
+    if (y_ahead)
+        for (int i = tid; i < N; i += RS_NT) s_y[RS_HL + i] = ym[i];
 
     for (int n = 0; n < a.n_batches; ++n) {
         const float* yb = ym + (int64_t)n * N;
+        const float step_size = a.step_size[n], bc2_sqrt = a.bc2_sqrt[n];  // requested early: used by the last stage
         RS_STAMP(0);
+#ifdef V2VAE_STAMPS
+        if (tid == 0 && model == 0 && n == a.n_batches - 1) reinterpret_cast<unsigned long long*>(a.ws)[12] = clock64();
+#endif
         // ---- parameters and samples to LDS
 #pragma unroll
         for (int q = 0; q < RS_APT; ++q) {
             const int idx = tid + q * RS_NT;
             if (idx < pack) s_par[idx] = pr[q];
         }
-        for (int i = tid; i < N; i += RS_NT) s_y[RS_HL + i] = yb[i];
+        // samples: short batches are fetched one step ahead into registers (the fetch latency hides behind the whole step)
+        float ynx[RS_YPT];
+        if (!y_ahead) {
+            for (int i = tid; i < N; i += RS_NT) s_y[RS_HL + i] = yb[i];
+        } else if (n + 1 < a.n_batches) {
+#pragma unroll
+            for (int q = 0; q < RS_YPT; ++q) {
+                const int i = tid + q * RS_NT;
+                ynx[q] = i < N ? yb[N + i] : 0.f;
+            }
+        }
         __syncthreads();
 
         RS_STAMP(1);
@@ -313,6 +362,9 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
             double kl = 0.0;
             double inv_den[MAX_C];
             posterior_temperatures<CB>(p_sc, C, nv, inv_den);
+            float prk[MAX_C];
+#pragma unroll
+            for (int k = 0; k < CB; ++k) prk[k] = k < C ? prior[k] : 1.f;
             for (int b = tid; b < B; b += RS_NT) {
                 const float x = s_x[b];
                 Posterior p;
@@ -322,7 +374,7 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
                 float klb = 0.f;
 #pragma unroll
                 for (int k = 0; k < CB; ++k)
-                    if (k < C) klb += p.q[k] * logf(p.q[k] / prior[k] + 1e-12f);
+                    if (k < C) klb += p.q[k] * logf(p.q[k] / prk[k] + 1e-12f);
                 if (b >= l.kl_lo && b < l.kl_hi) kl += (double)klb;
                 if (a.y_eq) a.y_eq[(int64_t)model * a.n_batches * B + (int64_t)n * B + b] = x;
             }
@@ -351,12 +403,26 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
             const int r = idx >> 6, k = (idx >> 3) & 7, j = idx & 7;
             const int d = k > j ? k - j : j - k, mn = k < j ? k : j;
             const int Tr = W > r ? (W - r + S - 1) / S : 0;  // windows of this phase
-            double tot = 0.0;
-            for (int w = 0; w < RS_NW; ++w) tot += (double)s_misc[RS_NT + w * 8 + d];
+            float tw[RS_NW];
+#pragma unroll
+            for (int w = 0; w < RS_NW; ++w) tw[w] = s_misc[RS_NT + w * 8 + d];
             const float* vb = s_mom + MP + 8;
-            double edge = 0.0;
-            for (int m = 0; m < mn; ++m) edge += (double)(vb[m] * vb[m + d]);
-            for (int m = Tr + mn; m < B; ++m) edge += (double)(vb[m] * vb[m + d]);
+            // edge terms: m < mn at the head (mn <= 7), m >= Tr + mn at the tail (a handful: B - Tr is about (L - 1) / S);
+            // fixed-length predicated loops keep the LDS reads independent of each other
+            float hd[8], tl[16];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) hd[m] = vb[m] * vb[m + d];
+            const int t0 = Tr + mn;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) tl[i] = vb[t0 + i] * vb[t0 + i + d];   // beyond the batch the moments read as zero
+            double tot = 0.0, edge = 0.0;
+#pragma unroll
+            for (int w = 0; w < RS_NW; ++w) tot += (double)tw[w];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) edge += m < mn ? (double)hd[m] : 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) edge += t0 + i < B ? (double)tl[i] : 0.0;
+            for (int m = t0 + 16; m < B; ++m) edge += (double)(vb[m] * vb[m + d]);
             s_P[idx] = (float)(tot - edge);
         }
 
@@ -364,17 +430,20 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
         // ---- ELBO expectations, one window per lane (lib/real_equalization.py:868-913 in window form)
         double Eacc = 0.0;
         for (int r = 0; r < S; ++r) {
-            float G[64], F[32];
+            float G2[2][8], F[32];
 #pragma unroll
-            for (int i = 0; i < 64; ++i) G[i] = 0.f;
+            for (int j = 0; j < 8; ++j) G2[0][j] = G2[1][j] = 0.f;
 #pragma unroll
             for (int i = 0; i < 32; ++i) F[i] = 0.f;
             const float4* Hq = reinterpret_cast<const float4*>(s_H + r * 64);
             const float4* HHq = reinterpret_cast<const float4*>(s_HH + r * 64);
             for (int c = 0; c < o.nchunks; ++c) {
+                RS_SUB(14, r == 0 && c == 0);
                 const int s0 = c * o.TS;
                 const int s1 = s0 + o.TS < B ? s0 + o.TS : B;
-                const int t = s0 - kmax + tid;
+                for (int sub = 0; sub < RS_SLOTS / RS_NT; ++sub) {
+                const int slot_w = tid + sub * RS_NT;
+                const int t = s0 - kmax + slot_w;
                 const int nn = t * S + r;
                 const bool valid = (t < s1) && nn >= 0 && nn < W;
                 const bool own = valid && t >= s0;
@@ -420,7 +489,11 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
                 const float e = A - yv;
                 const float En = e * e + 2.f * yv * (ps - psq) + pvs;
                 if (own) Eacc += (double)En;
+                RS_SUB(15, r == 0 && c == 0);
                 const float wo = own ? 1.f : 0.f;
+                // second pass over H: re-read the rows from LDS instead of keeping all 64 coefficients live across both passes
+                asm volatile("" ::: "memory");
+                float ak[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const float4 h0 = Hq[2 * k], h1v = Hq[2 * k + 1];
@@ -428,61 +501,78 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
                     hw = fmaf(h0.y, wq[1], hw); hw = fmaf(h0.z, wq[2], hw); hw = fmaf(h0.w, wq[3], hw);
                     hw = fmaf(h1v.x, wq[4], hw); hw = fmaf(h1v.y, wq[5], hw); hw = fmaf(h1v.z, wq[6], hw); hw = fmaf(h1v.w, wq[7], hw);
                     const float dk = dr[k], dqk = dqr[k];
-                    s_D[(0 * 8 + k) * RS_NT + tid] = vl * (2.f * e * z[k] + 2.f * hw);
-                    s_D[(1 * 8 + k) * RS_NT + tid] = vl * (2.f * A * dk - 2.f * yv * dqk + z[k] * z[k] + 4.f * tt[k]);
-                    s_D[(2 * 8 + k) * RS_NT + tid] = vl * (2.f * dk * z[k]);
+                    s_D[(0 * 8 + k) * RS_SLOTS + slot_w] = vl * (2.f * e * z[k] + 2.f * hw);
+                    s_D[(1 * 8 + k) * RS_SLOTS + slot_w] = vl * (2.f * A * dk - 2.f * yv * dqk + z[k] * z[k] + 4.f * tt[k]);
+                    s_D[(2 * 8 + k) * RS_SLOTS + slot_w] = vl * (2.f * dk * z[k]);
                     // parameter-gradient integrands of owned windows
-                    const float ak = wo * fmaf(e, mu[k], wq[k]);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) G[k * 8 + j] = fmaf(ak, mu[j], G[k * 8 + j]);
+                    ak[k] = wo * fmaf(e, mu[k], wq[k]);
                     F[k] += wo * (2.f * e * mu[k] + wq[k]);
                     F[8 + k] += wo * (2.f * A * vv[k] + 2.f * kp[k] * z[k] + 2.f * gm[k] * dk);
                     F[16 + k] += wo * (-2.f * yv * vv[k]);
                 }
-                s_vl[tid] = vl;
+                RS_SUB(16, r == 0 && c == 0);
+                rs_quad_outer<0>(G2, ak, mu, lane & 3);
+                rs_quad_outer<0xB1>(G2, ak, mu, lane & 3);
+                rs_quad_outer<0x4E>(G2, ak, mu, lane & 3);
+                rs_quad_outer<0x1B>(G2, ak, mu, lane & 3);
+                s_vl[slot_w] = vl;
+                }
+                RS_SUB(17, r == 0 && c == 0);
                 __syncthreads();
-                // gather: symbol m = s0 + tid collects window t = m - kk at compact tap kk
-                if (tid < o.TS && s0 + tid < s1) {
+                RS_SUB(18, r == 0 && c == 0);
+                // gather: symbol m = s0 + ml collects window t = m - kk at compact tap kk
+                for (int sub = 0; sub < RS_SLOTS / RS_NT; ++sub) {
+                const int ml = tid + sub * RS_NT;
+                if (ml < o.TS && s0 + ml < s1) {
                     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
                     for (int kk = 0; kk < 8; ++kk) {
                         const bool act = kk < LE;
-                        const int slot = act ? tid + kmax - kk : 0;
-                        const float d0 = s_D[(0 * 8 + kk) * RS_NT + slot], d1 = s_D[(1 * 8 + kk) * RS_NT + slot];
-                        const float d2 = s_D[(2 * 8 + kk) * RS_NT + slot], vs = s_vl[slot];
+                        const int slot = act ? ml + kmax - kk : 0;
+                        const float d0 = s_D[(0 * 8 + kk) * RS_SLOTS + slot], d1 = s_D[(1 * 8 + kk) * RS_SLOTS + slot];
+                        const float d2 = s_D[(2 * 8 + kk) * RS_SLOTS + slot], vs = s_vl[slot];
                         const float dk = s_d[r * 8 + kk];
                         a0 += act ? d0 : 0.f;
                         a1 += act ? d1 : 0.f;
                         a2 += act ? d2 : 0.f;
                         a3 = fmaf(act ? vs : 0.f, dk * dk, a3);
                     }
-                    float* gp = s_gm + s0 + tid;
+                    float* gp = s_gm + s0 + ml;
                     if (r == 0) { gp[0] = a0; gp[GP] = a1; gp[2 * GP] = a2; gp[3 * GP] = a3; }
                     else { gp[0] += a0; gp[GP] += a1; gp[2 * GP] += a2; gp[3 * GP] += a3; }
                 }
+                }
                 __syncthreads();
             }
-            // cross-lane sums: two butterfly steps in registers, then [slot][element] through LDS (pitch 97)
-            rs_quad_fold<64>(G, lane);
+            RS_SUB(19, r == 0);
+            // cross-lane sums: G is already folded over each quad, F takes two butterfly steps in registers; then
+            // [slot = quad][element] through LDS (pitch 97) and a fixed-order sum over the RS_NW * 16 slots
             rs_quad_fold<32>(F, lane);
             {
                 float* R = s_D + (wv * 16 + (lane >> 2)) * 97;
-                const int eg = (lane & 1) * 32 + ((lane >> 1) & 1) * 16, ef = 64 + (lane & 1) * 16 + ((lane >> 1) & 1) * 8;
+                const int eg = (lane & 3) * 16, ef = 64 + (lane & 1) * 16 + ((lane >> 1) & 1) * 8;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) R[eg + i] = G[i];
+                for (int j = 0; j < 8; ++j) { R[eg + j] = G2[0][j]; R[eg + 8 + j] = G2[1][j]; }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) R[ef + i] = F[i];
             }
             __syncthreads();
             {
-                const int e = tid >> 1, part = tid & 1;
+                constexpr int PER = RS_NW * 16 / RS_PARTS;  // slots per thread
+                const int e = tid / RS_PARTS, part = tid % RS_PARTS;
+                const float* Rp = s_D + part * PER * 97 + (e < RS_GREC ? e : 0);
+                float rv[PER];
+#pragma unroll
+                for (int i = 0; i < PER; ++i) rv[i] = Rp[i * 97];   // all loads in flight before the first add
                 float sacc = 0.f;
-                if (e < RS_GREC)
-                    for (int slot = part * (RS_NW * 8); slot < (part + 1) * (RS_NW * 8); ++slot) sacc += s_D[slot * 97 + e];
+#pragma unroll
+                for (int i = 0; i < PER; ++i) sacc += rv[i];
                 sacc += rs_quad_xor1(sacc);
+                if (RS_PARTS == 4) sacc += rs_quad_xor2(sacc);
                 if (e < RS_GREC && part == 0) s_gtot[r * RS_GREC + e] = sacc;
             }
             __syncthreads();
+            RS_SUB(20, r == 0);
         }
         RS_STAMP(6);
         E = rs_block_sum(Eacc, s_dbl, tid);
@@ -633,7 +723,6 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
         RS_STAMP(10);
         // ---- Adam with AMSGrad (torch.optim.Adam single-tensor arithmetic), noise variance, loss
         {
-            const float step_size = a.step_size[n], bc2_sqrt = a.bc2_sqrt[n];
 #pragma unroll
             for (int q = 0; q < RS_APT; ++q) {
                 const int idx = tid + q * RS_NT;
@@ -647,11 +736,21 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
                     pr[q] = pr[q] - step_size * (mi / denom);
                 }
             }
+            if (y_ahead && n + 1 < a.n_batches) {
+#pragma unroll
+                for (int q = 0; q < RS_YPT; ++q) {
+                    const int i = tid + q * RS_NT;
+                    if (i < N) s_y[RS_HL + i] = ynx[q];
+                }
+            }
             if (a.adaptive_noise) nv = (float)(E / (double)W);
             if (tid == 0 && a.loss_curve) a.loss_curve[(int64_t)model * a.n_batches + n] = (float)loss;
         }
         __syncthreads();
         RS_STAMP(11);
+#ifdef V2VAE_STAMPS
+        if (tid == 0 && model == 0 && n == a.n_batches - 1) reinterpret_cast<unsigned long long*>(a.ws)[13] = clock64();
+#endif
     }
 
     // ---- state back to global memory
