@@ -31,12 +31,13 @@ constexpr int RS_NW = RS_NT / 64;   // waves
 constexpr int RS_HL = 32;           // zero samples kept left of the batch in LDS
 constexpr int RS_APT = 8;           // optimiser elements per thread (parameter pack <= RS_APT * RS_NT)
 constexpr int RS_YPT = 8;           // samples per thread fetched one batch ahead (batches up to RS_YPT * RS_NT samples)
+constexpr int RS_QCACHE = 4;        // posteriors of up to this many levels are kept in LDS between forward and backward
 constexpr int RS_GREC = 96;         // per-wave, per-phase record: G 8x8 | f1 8 | f2 8 | f3 8 | pad 8
 
 typedef float rs_f16 __attribute__((ext_vector_type(16)));
 
 struct RsOff {  // LDS carve in floats
-    int y, x, gx, mom, MP, gm, GP, D, vl, H, HH, h1c, d, dq, par, grad, gtot, P, misc, dbl, total;
+    int y, x, gx, q, mom, MP, gm, GP, D, vl, H, HH, h1c, d, dq, par, grad, gtot, P, misc, dbl, total;
     int nchunks, TS, packp;
     int c0, o1, o2;  // equaliser sample window: X_b[i] = y[b S + c0 - i], i < 32; first-order tap j at o1 - j, lag j at o2 + j
 };
@@ -69,6 +70,7 @@ int rs_plan(const Lay& l, int64_t pack, RsOff* o) {
     r.mom = take(4 * r.MP);
     r.GP = rs_rup(B, 4);
     r.gm = take(4 * r.GP);
+    r.q = take(l.C <= RS_QCACHE ? RS_QCACHE * r.GP : 4);
     {   // per-window gradient image of the ELBO stage; later the cross-lane reduction image (64 slots, pitch 97) and the
         // cross-wave image of the equaliser-gradient tiles
         int nd = 3 * 8 * RS_SLOTS;
@@ -222,6 +224,7 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
     float* s_gx = sm + o.gx;
     float* s_mom = sm + o.mom;
     float* s_gm = sm + o.gm;
+    float* s_q = sm + o.q;
     float* s_D = sm + o.D;
     float* s_vl = sm + o.vl;
     float* s_H = sm + o.H;
@@ -371,6 +374,10 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
                 posterior<CB>(x, levels, inv_den, C, p);
                 float* mo = s_mom + 8 + b;
                 mo[0] = p.mu; mo[MP] = p.var; mo[2 * MP] = p.kap; mo[3 * MP] = p.gam;
+                if (CB <= RS_QCACHE) {
+#pragma unroll
+                    for (int k = 0; k < CB; ++k) s_q[k * GP + b] = p.q[k];
+                }
                 float klb = 0.f;
 #pragma unroll
                 for (int k = 0; k < CB; ++k)
@@ -581,48 +588,65 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
         const float lam = (float)lamd;
 
         RS_STAMP(7);
-        // ---- per-symbol backward: moments -> posterior -> equaliser output, noise scaling (softmax backward in double)
+        // ---- per-symbol backward: moments -> posterior -> equaliser output, noise scaling.
+        // Softmax backward in the pairwise form dz_k = q_k sum_j q_j (v_k - v_j): every term is a product of a (possibly
+        // tiny) probability with an O(1) difference, so there is no cancellation against the posterior mean of v and
+        // single precision suffices.
         {
             float gs[MAX_C];
 #pragma unroll
             for (int k = 0; k < CB; ++k) gs[k] = 0.f;
-            double inv_den[MAX_C], inv_den_sc[MAX_C];
+            double inv_den[MAX_C];
             posterior_temperatures<CB>(p_sc, C, nv, inv_den);
+            float idn[MAX_C], idsc[MAX_C], lvk[MAX_C], prk[MAX_C];
 #pragma unroll
-            for (int k = 0; k < CB; ++k) inv_den_sc[k] = k < C ? inv_den[k] / (double)p_sc[k] : 0.0;
+            for (int k = 0; k < CB; ++k) {
+                idn[k] = (float)inv_den[k];
+                idsc[k] = k < C ? (float)(inv_den[k] / (double)p_sc[k]) : 0.f;
+                lvk[k] = k < C ? levels[k] : 0.f;
+                prk[k] = k < C ? prior[k] : 1.f;
+            }
             for (int b = tid; b < B; b += RS_NT) {
                 const float x = s_x[b];
-                Posterior p;
-                posterior<CB>(x, levels, inv_den, C, p);
+                float q[MAX_C], pmu, pvar, pkap;
+                if (CB <= RS_QCACHE) {  // posterior kept from the forward stage
+#pragma unroll
+                    for (int k = 0; k < CB; ++k) q[k] = s_q[k * GP + b];
+                    const float* mo = s_mom + 8 + b;
+                    pmu = mo[0]; pvar = mo[MP]; pkap = mo[2 * MP];
+                } else {
+                    Posterior p;
+                    posterior<CB>(x, levels, inv_den, C, p);
+#pragma unroll
+                    for (int k = 0; k < CB; ++k) q[k] = p.q[k];
+                    pmu = p.mu; pvar = p.var; pkap = p.kap;
+                }
                 const float* g = s_gm + b;
                 const float gmu = g[0], gv = g[GP], gk = g[2 * GP], gg = g[3 * GP];
                 const bool in_kl = b >= l.kl_lo && b < l.kl_hi;
-                double dq[MAX_C];
-                double qdq = 0.0;
+                float v[MAX_C];
+#pragma unroll
+                for (int k = 0; k < CB; ++k) {
+                    const float d = lvk[k] - pmu, d2 = d * d;
+                    float vk = gmu * d + gv * d2 + gk * (d2 * d - 3.f * pvar * d) + gg * (d2 * d2 - 4.f * pkap * d - 6.f * pvar * d2);
+                    vk *= lam;
+                    if (in_kl) vk += logf(q[k] / prk[k] + 1e-12f) + q[k] / (q[k] + 1e-12f * prk[k]);
+                    v[k] = vk;
+                }
+                float gxa = 0.f;
 #pragma unroll
                 for (int k = 0; k < CB; ++k)
                     if (k < C) {
-                        const double d = (double)levels[k] - (double)p.mu, d2 = d * d;
-                        double v = (double)gmu * d + (double)gv * d2 + (double)gk * (d2 * d - 3.0 * (double)p.var * d) +
-                                   (double)gg * (d2 * d2 - 4.0 * (double)p.kap * d - 6.0 * (double)p.var * d2);
-                        v *= (double)lam;
-                        if (in_kl) {
-                            const float prk = prior[k];
-                            v += (double)(logf(p.q[k] / prk + 1e-12f) + p.q[k] / (p.q[k] + 1e-12f * prk));
-                        }
-                        dq[k] = v;
-                        qdq += (double)p.q[k] * v;
-                    }
-                double gxd = 0.0;
+                        float sk = 0.f;
 #pragma unroll
-                for (int k = 0; k < CB; ++k)
-                    if (k < C) {
-                        const double dz = (double)p.q[k] * (dq[k] - qdq);
-                        const double df = (double)x - (double)levels[k];
-                        gxd += dz * (-2.0 * df * inv_den[k]);
-                        gs[k] += (float)(dz * df * df * inv_den_sc[k]);
+                        for (int j = 0; j < CB; ++j)
+                            if (j < C && j != k) sk = fmaf(q[j], v[k] - v[j], sk);
+                        const float dz = q[k] * sk;
+                        const float df = x - lvk[k];
+                        gxa = fmaf(dz, -2.f * df * idn[k], gxa);
+                        gs[k] = fmaf(dz * df, df * idsc[k], gs[k]);
                     }
-                s_gx[b] = (float)gxd;
+                s_gx[b] = gxa;
             }
 #pragma unroll
             for (int k = 0; k < CB; ++k) {

@@ -490,35 +490,38 @@ __device__ __forceinline__ void d_sym_bwd(const GridCtx gc, Lay l, const float* 
                     posterior<CB>(x, lv, inv_den[c], l.C, p);
                     const float* g = gmom + (int64_t)c * 4 * l.sym_cnt + i;
                     const float gmu = g[0], gv = g[l.sym_cnt], gk = g[2 * l.sym_cnt], gg = g[3 * l.sym_cnt];
-                    // Softmax backward cancels dq against its posterior mean; for peaked posteriors the
-                    // difference is many orders below dq itself, so this short chain runs in double.
-                    double dq[MAX_C];
-                    double qdq = 0.0;
+                    // Softmax backward in the pairwise form dz_k = q_k sum_j q_j (v_k - v_j): each term is a product of a
+                    // (possibly tiny) probability with an O(1) difference, so nothing cancels against the posterior mean
+                    // of v (which for peaked posteriors would be many orders above the result) and fp32 suffices.
+                    float v[MAX_C];
 #pragma unroll
                     for (int k = 0; k < CB; ++k)
                         if (k < l.C) {
-                            const double d = (double)lv[k] - (double)p.mu, d2 = d * d;
-                            double v = (double)gmu * d + (double)gv * d2 + (double)gk * (d2 * d - 3.0 * (double)p.var * d) +
-                                       (double)gg * (d2 * d2 - 4.0 * (double)p.kap * d - 6.0 * (double)p.var * d2);
-                            v *= (double)lam;
+                            const float d = lv[k] - p.mu, d2 = d * d;
+                            float vk = gmu * d + gv * d2 + gk * (d2 * d - 3.f * p.var * d) +
+                                       gg * (d2 * d2 - 4.f * p.kap * d - 6.f * p.var * d2);
+                            vk *= lam;
                             if (in_kl) {
                                 const float pr = prior[c * l.C + k];
-                                v += (double)(logf(p.q[k] / pr + 1e-12f) + p.q[k] / (p.q[k] + 1e-12f * pr));
+                                vk += logf(p.q[k] / pr + 1e-12f) + p.q[k] / (p.q[k] + 1e-12f * pr);
                             }
-                            v *= (double)gsc;
-                            dq[k] = v;
-                            qdq += (double)p.q[k] * v;
+                            v[k] = vk * gsc;
                         }
-                    double gxd = 0.0;
+                    float gxa = 0.f;
 #pragma unroll
                     for (int k = 0; k < CB; ++k)
                         if (k < l.C) {
-                            const double dz = (double)p.q[k] * (dq[k] - qdq);
-                            const double df = (double)x - (double)lv[k];
-                            gxd += dz * (-2.0 * df * inv_den[c][k]);
-                            gs[c][k] += (float)(dz * df * df * inv_den[c][k] / (double)sc[k]);
+                            float sk = 0.f;
+#pragma unroll
+                            for (int j = 0; j < CB; ++j)
+                                if (j < l.C && j != k) sk = fmaf(p.q[j], v[k] - v[j], sk);
+                            const float dz = p.q[k] * sk;
+                            const float df = x - lv[k];
+                            const float idn = (float)inv_den[c][k];
+                            gxa = fmaf(dz, -2.f * df * idn, gxa);
+                            gs[c][k] = fmaf(dz * df, df * (idn / sc[k]), gs[c][k]);
                         }
-                    gx = (float)gxd;
+                    gx = gxa;
                 }
                 gxhat[(int64_t)c * l.sym_cnt + i] = gx;
             }
