@@ -35,6 +35,7 @@ constexpr int RS_QCACHE = 4;        // posteriors of up to this many levels are 
 constexpr int RS_GREC = 96;         // per-wave, per-phase record: G 8x8 | f1 8 | f2 8 | f3 8 | pad 8
 
 typedef float rs_f16 __attribute__((ext_vector_type(16)));
+typedef float rs_f2 __attribute__((ext_vector_type(2)));
 
 struct RsOff {  // LDS carve in floats
     int y, x, gx, q, mom, MP, gm, GP, D, vl, H, HH, h1c, d, dq, par, grad, gtot, P, misc, dbl, total;
@@ -442,12 +443,27 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
             for (int j = 0; j < 8; ++j) G2[0][j] = G2[1][j] = 0.f;
 #pragma unroll
             for (int i = 0; i < 32; ++i) F[i] = 0.f;
-            const float4* Hq = reinterpret_cast<const float4*>(s_H + r * 64);
-            const float4* HHq = reinterpret_cast<const float4*>(s_HH + r * 64);
+            // tables of this phase in registers, as pairs: H is symmetric, so "row j" is also "column j" and
+            // u += H[:, j] mu[j] runs as packed two-wide FMAs over adjacent elements of row j
+            rs_f2 Hr[8][4], h1p[4], dp[4], dqp[4];
+            const rs_f2* gq = reinterpret_cast<const rs_f2*>(s_HH + r * 64);  // (H.H) rows are read where used
+            {
+                const rs_f2* hq = reinterpret_cast<const rs_f2*>(s_H + r * 64);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int kp = 0; kp < 4; ++kp) Hr[j][kp] = hq[j * 4 + kp];
+                const rs_f2* t1 = reinterpret_cast<const rs_f2*>(s_h1c + r * 8);
+                const rs_f2* t2 = reinterpret_cast<const rs_f2*>(s_d + r * 8);
+                const rs_f2* t3 = reinterpret_cast<const rs_f2*>(s_dq + r * 8);
+#pragma unroll
+                for (int kp = 0; kp < 4; ++kp) { h1p[kp] = t1[kp]; dp[kp] = t2[kp]; dqp[kp] = t3[kp]; }
+            }
             for (int c = 0; c < o.nchunks; ++c) {
                 RS_SUB(14, r == 0 && c == 0);
                 const int s0 = c * o.TS;
                 const int s1 = s0 + o.TS < B ? s0 + o.TS : B;
+#pragma unroll 1
                 for (int sub = 0; sub < RS_SLOTS / RS_NT; ++sub) {
                 const int slot_w = tid + sub * RS_NT;
                 const int t = s0 - kmax + slot_w;
@@ -461,28 +477,20 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
                 float mu[8], vv[8], kp[8], gm[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { mu[k] = mb[k]; vv[k] = mb[MP + k]; kp[k] = mb[2 * MP + k]; gm[k] = mb[3 * MP + k]; }
-                float h1r[8], dr[8], dqr[8];
-                {
-                    const float4* t1 = reinterpret_cast<const float4*>(s_h1c + r * 8);
-                    const float4* t2 = reinterpret_cast<const float4*>(s_d + r * 8);
-                    const float4* t3 = reinterpret_cast<const float4*>(s_dq + r * 8);
-                    const float4 a0 = t1[0], a1 = t1[1], b0 = t2[0], b1 = t2[1], c0 = t3[0], c1 = t3[1];
-                    h1r[0] = a0.x; h1r[1] = a0.y; h1r[2] = a0.z; h1r[3] = a0.w; h1r[4] = a1.x; h1r[5] = a1.y; h1r[6] = a1.z; h1r[7] = a1.w;
-                    dr[0] = b0.x; dr[1] = b0.y; dr[2] = b0.z; dr[3] = b0.w; dr[4] = b1.x; dr[5] = b1.y; dr[6] = b1.z; dr[7] = b1.w;
-                    dqr[0] = c0.x; dqr[1] = c0.y; dqr[2] = c0.z; dqr[3] = c0.w; dqr[4] = c1.x; dqr[5] = c1.y; dqr[6] = c1.z; dqr[7] = c1.w;
-                }
+                // pass 1: u = H mu, tt = (H.H) v
+                rs_f2 u2[4], t2[4];
+#pragma unroll
+                for (int kq = 0; kq < 4; ++kq) { u2[kq] = Hr[0][kq] * mu[0]; t2[kq] = gq[kq] * vv[0]; }
+#pragma unroll
+                for (int j = 1; j < 8; ++j)
+#pragma unroll
+                    for (int kq = 0; kq < 4; ++kq) { u2[kq] += Hr[j][kq] * mu[j]; t2[kq] += gq[j * 4 + kq] * vv[j]; }
                 float z[8], tt[8], wq[8];
                 float pa = 0.f, pq = 0.f, ps = 0.f, psq = 0.f, pvs = 0.f;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const float4 h0 = Hq[2 * k], h1v = Hq[2 * k + 1], g0 = HHq[2 * k], g1 = HHq[2 * k + 1];
-                    float u = h0.x * mu[0];
-                    u = fmaf(h0.y, mu[1], u); u = fmaf(h0.z, mu[2], u); u = fmaf(h0.w, mu[3], u);
-                    u = fmaf(h1v.x, mu[4], u); u = fmaf(h1v.y, mu[5], u); u = fmaf(h1v.z, mu[6], u); u = fmaf(h1v.w, mu[7], u);
-                    float tk = g0.x * vv[0];
-                    tk = fmaf(g0.y, vv[1], tk); tk = fmaf(g0.z, vv[2], tk); tk = fmaf(g0.w, vv[3], tk);
-                    tk = fmaf(g1.x, vv[4], tk); tk = fmaf(g1.y, vv[5], tk); tk = fmaf(g1.z, vv[6], tk); tk = fmaf(g1.w, vv[7], tk);
-                    const float h1k = h1r[k], dk = dr[k], dqk = dqr[k];
+                    const float u = u2[k >> 1][k & 1], tk = t2[k >> 1][k & 1];
+                    const float h1k = h1p[k >> 1][k & 1], dk = dp[k >> 1][k & 1], dqk = dqp[k >> 1][k & 1];
                     const float zk = fmaf(2.f, u, h1k);
                     pa = fmaf(h1k, mu[k], pa);
                     pq = fmaf(mu[k], u, pq);
@@ -498,20 +506,22 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
                 if (own) Eacc += (double)En;
                 RS_SUB(15, r == 0 && c == 0);
                 const float wo = own ? 1.f : 0.f;
-                // second pass over H: re-read the rows from LDS instead of keeping all 64 coefficients live across both passes
-                asm volatile("" ::: "memory");
+                // pass 2: H w, per-(window, tap) gradients of the moments, parameter-gradient integrands of owned windows
+                rs_f2 hw2[4];
+#pragma unroll
+                for (int kq = 0; kq < 4; ++kq) hw2[kq] = Hr[0][kq] * wq[0];
+#pragma unroll
+                for (int j = 1; j < 8; ++j)
+#pragma unroll
+                    for (int kq = 0; kq < 4; ++kq) hw2[kq] += Hr[j][kq] * wq[j];
                 float ak[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const float4 h0 = Hq[2 * k], h1v = Hq[2 * k + 1];
-                    float hw = h0.x * wq[0];
-                    hw = fmaf(h0.y, wq[1], hw); hw = fmaf(h0.z, wq[2], hw); hw = fmaf(h0.w, wq[3], hw);
-                    hw = fmaf(h1v.x, wq[4], hw); hw = fmaf(h1v.y, wq[5], hw); hw = fmaf(h1v.z, wq[6], hw); hw = fmaf(h1v.w, wq[7], hw);
-                    const float dk = dr[k], dqk = dqr[k];
+                    const float hw = hw2[k >> 1][k & 1];
+                    const float dk = dp[k >> 1][k & 1], dqk = dqp[k >> 1][k & 1];
                     s_D[(0 * 8 + k) * RS_SLOTS + slot_w] = vl * (2.f * e * z[k] + 2.f * hw);
                     s_D[(1 * 8 + k) * RS_SLOTS + slot_w] = vl * (2.f * A * dk - 2.f * yv * dqk + z[k] * z[k] + 4.f * tt[k]);
                     s_D[(2 * 8 + k) * RS_SLOTS + slot_w] = vl * (2.f * dk * z[k]);
-                    // parameter-gradient integrands of owned windows
                     ak[k] = wo * fmaf(e, mu[k], wq[k]);
                     F[k] += wo * (2.f * e * mu[k] + wq[k]);
                     F[8 + k] += wo * (2.f * A * vv[k] + 2.f * kp[k] * z[k] + 2.f * gm[k] * dk);
