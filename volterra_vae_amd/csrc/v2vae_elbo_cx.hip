@@ -759,23 +759,39 @@ __device__ __forceinline__ float cx_s_at(const Lay& l, const float* __restrict__
     return mom[(int64_t)1 * l.sym_cnt + (m - l.sym_lo)] + mom[(int64_t)5 * l.sym_cnt + (m - l.sym_lo)];
 }
 
+constexpr int PS_PER = 8;               // symbols per thread and tile
+constexpr int PS_TILE = NT * PS_PER;    // symbols per tile; the tile's s values plus 16 of halo are staged in LDS
+
 __global__ __launch_bounds__(NT) void k_psum_cx(Lay l, float* __restrict__ ws) {
     __shared__ double red[NT / 64][16];
+    __shared__ float s_s[PS_TILE + 16];
     const float* __restrict__ mom = ws + l.o_mom;
     double acc[16];
 #pragma unroll
     for (int d = 0; d < 16; ++d) acc[d] = 0.0;
-    for (int64_t j = (int64_t)blockIdx.x * NT + threadIdx.x; j < l.own_cnt; j += (int64_t)gridDim.x * NT) {
-        const int64_t m = l.own_lo + j;
-        const float s0 = cx_s_at(l, mom, m);
+    const int64_t ntile = (l.own_cnt + PS_TILE - 1) / PS_TILE;
+    for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int64_t m0 = l.own_lo + tile * PS_TILE;
+        __syncthreads();
+        for (int i = threadIdx.x; i < PS_TILE + 16; i += NT) s_s[i] = cx_s_at(l, mom, m0 + i);
+        __syncthreads();
+        float part[16];
 #pragma unroll
-        for (int d = 0; d < 16; ++d)
-            if (d <= l.kmax) acc[d] += (double)(s0 * cx_s_at(l, mom, m + d));
+        for (int d = 0; d < 16; ++d) part[d] = 0.f;
+#pragma unroll
+        for (int q = 0; q < PS_PER; ++q) {
+            const int i = threadIdx.x + q * NT;
+            const float s0 = (m0 + i < l.own_lo + l.own_cnt) ? s_s[i] : 0.f;
+#pragma unroll
+            for (int d = 0; d < 16; ++d) part[d] = fmaf(s0, s_s[i + d], part[d]);
+        }
+#pragma unroll
+        for (int d = 0; d < 16; ++d) acc[d] += (double)part[d];
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int d = 0; d < 16; ++d) {
-        double v = acc[d];
+        double v = d <= l.kmax ? acc[d] : 0.0;
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
         if (lane == 0) red[wv][d] = v;
     }
