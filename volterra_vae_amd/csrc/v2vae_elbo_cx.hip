@@ -914,9 +914,8 @@ void launch_psum_cx(const Lay& l, float* ws, hipStream_t st) {
     hipLaunchKernelGGL(k_psum_finish_cx, dim3(1), dim3(NT), 0, st, l, ws);
 }
 
-void launch_finish_channel_cx(const Lay& l, float* ws, const double* scal, const float* grad_scale, float* g_h1, float* g_h2,
-                              hipStream_t st) {
-    launch_sum_records(l, ws + l.o_part_cx, l.S * CX_REC, l.nblk_cx, ws + l.o_sumstage, ws + l.o_tot_cx, st);
+void launch_chain_channel_cx(const Lay& l, float* ws, const double* scal, const float* grad_scale, float* g_h1, float* g_h2,
+                             hipStream_t st) {
     const int n = 2 * l.L + 2 * l.L * l.L;
     hipLaunchKernelGGL(k_chain_channel_cx, dim3((n + NT - 1) / NT), dim3(NT), 0, st, l, (const float*)ws, scal, grad_scale, g_h1, g_h2);
 }

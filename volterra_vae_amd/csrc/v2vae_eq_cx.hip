@@ -221,8 +221,7 @@ int launch_eq_bwd_cx(const Lay& l, const float* y, const float* gx, float* ws, h
     return V2VAE_OK;
 }
 
-void launch_finish_equaliser_cx(const Lay& l, float* ws, float* g_k1, float* g_k2, hipStream_t st) {
-    launch_sum_records(l, ws + l.o_part_eqcx, 4096, l.nblk_eq, ws + l.o_sumstage, ws + l.o_tot_eqcx, st);
+void launch_chain_equaliser_cx(const Lay& l, float* ws, float* g_k1, float* g_k2, hipStream_t st) {
     const int n = 2 * l.l1 + 2 * l.l2 * l.l2;
     hipLaunchKernelGGL(k_chain_equaliser_cx, dim3((n + NT - 1) / NT), dim3(NT), 0, st, l, (const float*)ws, g_k1, g_k2);
 }

@@ -178,7 +178,8 @@ int make_layout(const v2vae_problem* p, Lay* out) {
         if (l.rec_sym > mx) mx = l.rec_sym;
         if (l.S * CX_REC > mx) mx = l.S * CX_REC;
         if (4096 > mx) mx = 4096;
-        l.o_sumstage = take((int64_t)SUM_CHUNKS * mx);
+        l.sumstage_stride = (int64_t)SUM_CHUNKS * mx;
+        l.o_sumstage = take(3 * l.sumstage_stride);
     }
     l.o_Epart = take(2 * (int64_t)(l.nblk_elbo > l.nblk_cx ? l.nblk_elbo : l.nblk_cx));
     l.o_KLpart = take(2 * (int64_t)l.nblk_sym);
@@ -1026,6 +1027,13 @@ __device__ __forceinline__ void d_finalize_scalars(const GridCtx gc, double W, d
     }
 }
 
+// single-GPU step: both in one launch (thread 0 writes E and KL and then reads them back itself)
+__global__ __launch_bounds__(NT) void k_reduce_finalize_scalars(Lay l, const float* ws, double* scal) {
+    const GridCtx one{0, 1};
+    d_reduce_scalars(one, l, ws, scal);
+    d_finalize_scalars(one, (double)l.W, scal);
+}
+
 __global__ void k_finalize_scalars(double W, double* __restrict__ scal) {
     d_finalize_scalars(GridCtx{(int)blockIdx.x, (int)gridDim.x}, W, scal);
 }
@@ -1074,6 +1082,51 @@ void launch_sum_records(const Lay& l, const float* part, int rec, int nrec, floa
     const int chunks = (nrec + per - 1) / per;
     hipLaunchKernelGGL(k_sum_records, dim3(gx, chunks), dim3(NT), 0, st, part, rec, nrec, per, stage);
     hipLaunchKernelGGL(k_sum_records, dim3(gx, 1), dim3(NT), 0, st, (const float*)stage, rec, chunks, chunks, tot);
+}
+
+// Up to three record sets summed by one launch per stage (same chunking and order as launch_sum_records).
+struct SumSet {
+    const float* part;
+    float* stage;
+    float* tot;
+    int rec, nrec, per, chunks;
+};
+struct SumSets {
+    SumSet s[3];
+    int n;
+};
+
+__global__ __launch_bounds__(NT) void k_sum_multi(SumSets ss, int second) {
+    const SumSet q = ss.s[blockIdx.z];
+    const GridCtx gc{(int)blockIdx.x, (int)gridDim.x};
+    if (!second) {
+        if ((int)blockIdx.y >= q.chunks) return;
+        d_sum_records(gc, (int)blockIdx.y, q.part, q.rec, q.nrec, q.per, q.chunks > 1 ? q.stage : q.tot);
+    } else if (q.chunks > 1) {
+        d_sum_records(gc, 0, q.stage, q.rec, q.chunks, q.chunks, q.tot);
+    }
+}
+
+static void sum_sets_add(SumSets& ss, const float* part, int rec, int nrec, float* stage, float* tot) {
+    if (rec <= 0) return;
+    SumSet& q = ss.s[ss.n++];
+    q.part = part; q.stage = stage; q.tot = tot; q.rec = rec; q.nrec = nrec;
+    if (nrec <= SUM_CHUNKS) { q.per = nrec; q.chunks = 1; }
+    else { q.per = (nrec + SUM_CHUNKS - 1) / SUM_CHUNKS; q.chunks = (nrec + q.per - 1) / q.per; }
+}
+
+static void sum_sets_launch(const SumSets& ss, hipStream_t st) {
+    if (ss.n == 0) return;
+    int gx = 1, gy = 1;
+    bool two = false;
+    for (int i = 0; i < ss.n; ++i) {
+        const int g = (ss.s[i].rec + NT - 1) / NT;
+        if (g > gx) gx = g;
+        if (ss.s[i].chunks > gy) gy = ss.s[i].chunks;
+        two = two || ss.s[i].chunks > 1;
+    }
+    hipLaunchKernelGGL(k_sum_multi, dim3(gx, gy, ss.n), dim3(NT), 0, st, ss, 0);
+    if (two) hipLaunchKernelGGL(k_sum_multi, dim3(gx, 1, ss.n), dim3(NT), 0, st, ss, 1);
 }
 
 // dE/dHs[o][a][b] on original stacked taps from the per-phase compact totals
@@ -1524,22 +1577,25 @@ int v2vae_finish_grads(const v2vae_problem* p, void* ws, const double* scal, con
     if (!ws || !scal) return V2VAE_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     float* w = (float*)ws;
+    SumSets ss{};
+    float* stage = w + l.o_sumstage;
+    if ((which & 1) && l.use_cx) sum_sets_add(ss, w + l.o_part_cx, l.S * CX_REC, l.nblk_cx, stage, w + l.o_tot_cx);
+    else if (which & 1) sum_sets_add(ss, w + l.o_part_elbo, l.rec_elbo, l.nblk_elbo, stage, w + l.o_tot_elbo);
+    if (which & 2) sum_sets_add(ss, w + l.o_part_sym, l.rec_sym, l.nblk_sym, stage + l.sumstage_stride, w + l.o_tot_sym);
+    if ((which & 4) && l.use_eqcx) sum_sets_add(ss, w + l.o_part_eqcx, 4096, l.nblk_eq, stage + 2 * l.sumstage_stride, w + l.o_tot_eqcx);
+    else if (which & 4) sum_sets_add(ss, w + l.o_part_eq, l.rec_eq, l.nblk_eq, stage + 2 * l.sumstage_stride, w + l.o_tot_eq);
+    sum_sets_launch(ss, st);
     if ((which & 1) && l.use_cx) {
-        launch_finish_channel_cx(l, w, scal, grad_scale, g_h1, g_h2, st);
+        launch_chain_channel_cx(l, w, scal, grad_scale, g_h1, g_h2, st);
     } else if (which & 1) {
-        launch_sum_records(l, w + l.o_part_elbo, l.rec_elbo, l.nblk_elbo, w + l.o_sumstage, w + l.o_tot_elbo, st);
         const int n = l.ns * l.L + l.ns * l.L * l.L;
         hipLaunchKernelGGL(k_chain_channel, dim3((n + NT - 1) / NT), dim3(NT), 0, st, l, (const float*)w, scal, grad_scale, g_h1, g_h2);
     }
-    if (which & 2) {
-        launch_sum_records(l, w + l.o_part_sym, l.rec_sym, l.nblk_sym, w + l.o_sumstage, w + l.o_tot_sym, st);
-        if (g_scaling)
-            hipLaunchKernelGGL(k_copy, dim3((l.rec_sym + NT - 1) / NT), dim3(NT), 0, st, (const float*)(w + l.o_tot_sym), g_scaling, l.rec_sym);
-    }
+    if ((which & 2) && g_scaling)
+        hipLaunchKernelGGL(k_copy, dim3((l.rec_sym + NT - 1) / NT), dim3(NT), 0, st, (const float*)(w + l.o_tot_sym), g_scaling, l.rec_sym);
     if ((which & 4) && l.use_eqcx) {
-        launch_finish_equaliser_cx(l, w, g_k1, g_k2, st);
+        launch_chain_equaliser_cx(l, w, g_k1, g_k2, st);
     } else if (which & 4) {
-        launch_sum_records(l, w + l.o_part_eq, l.rec_eq, l.nblk_eq, w + l.o_sumstage, w + l.o_tot_eq, st);
         const int n = l.ns * l.l1 + l.ns * l.l2 * l.l2;
         hipLaunchKernelGGL(k_chain_equaliser, dim3((n + NT - 1) / NT), dim3(NT), 0, st, l, (const float*)w, g_k1, g_k2);
     }
@@ -1584,8 +1640,12 @@ int v2vae_train_step(const v2vae_problem* p, const v2vae_train_args* a, void* st
     if ((rc = v2vae_eq_fwd(p, a->y, a->ws, a->xhat, stream))) return rc;
     if ((rc = v2vae_demap_moments(p, a->xhat, a->levels, a->prior, sc, a->noise_var, a->ws, nullptr, stream))) return rc;
     if ((rc = v2vae_elbo_fused(p, a->y, a->ws, stream))) return rc;
-    if ((rc = v2vae_reduce_scalars(p, a->ws, a->scal, stream))) return rc;
-    if ((rc = v2vae_finalize_scalars(p, a->scal, stream))) return rc;
+    {
+        Lay l;
+        if ((rc = make_layout(p, &l))) return rc;
+        if (!a->ws || !a->scal) return V2VAE_EINVAL;
+        hipLaunchKernelGGL(k_reduce_finalize_scalars, dim3(1), dim3(NT), 0, (hipStream_t)stream, l, (const float*)a->ws, a->scal);
+    }
     if ((rc = v2vae_sym_bwd(p, a->xhat, a->levels, a->prior, sc, a->noise_var, a->scal, nullptr, a->ws, a->gxhat, stream))) return rc;
     if ((rc = v2vae_eq_bwd(p, a->y, a->gxhat, a->ws, stream))) return rc;
     if ((rc = v2vae_finish_grads(p, a->ws, a->scal, nullptr, 7, g, g + n[0], g + n[0] + n[1], n[3] ? g + n[0] + n[1] + n[2] : nullptr,

@@ -53,7 +53,8 @@ struct Lay {
     // matrix-core equaliser path
     int use_eqcx, eqcx_lk, eqcx_steps;
     int64_t o_eqcxA, o_part_eqcx, o_tot_eqcx;
-    int64_t o_sumstage;      // [SUM_CHUNKS][largest record] staging of the two-stage record sums
+    int64_t o_sumstage;      // 3 x [SUM_CHUNKS][largest record] staging of the two-stage record sums (one per record set)
+    int64_t sumstage_stride; // floats between the three staging areas
     // record sizes of the per-workgroup partial sums (floats)
     int rec_elbo, rec_eq, rec_sym;
     // workspace offsets in floats
@@ -71,8 +72,8 @@ int make_layout(const v2vae_problem* p, Lay* out);
 // v2vae_elbo_cx.hip
 int launch_elbo_cx(const Lay& l, const float* y, float* ws, hipStream_t st);
 void launch_psum_cx(const Lay& l, float* ws, hipStream_t st);
-void launch_finish_channel_cx(const Lay& l, float* ws, const double* scal, const float* grad_scale, float* g_h1, float* g_h2,
-                              hipStream_t st);
+void launch_chain_channel_cx(const Lay& l, float* ws, const double* scal, const float* grad_scale, float* g_h1, float* g_h2,
+                             hipStream_t st);
 
 // two-stage deterministic sum of nrec records of `rec` floats: tot[e] = sum_b part[b][e]  (v2vae_kernels.hip)
 void launch_sum_records(const Lay& l, const float* part, int rec, int nrec, float* stage, float* tot, hipStream_t st);
@@ -81,7 +82,7 @@ void launch_sum_records(const Lay& l, const float* part, int rec, int nrec, floa
 int launch_prep_eqcx(const Lay& l, const float* k1, const float* k2, float* ws, hipStream_t st);
 int launch_eq_fwd_cx(const Lay& l, const float* y, const float* ws, float* xhat, hipStream_t st);
 int launch_eq_bwd_cx(const Lay& l, const float* y, const float* gx, float* ws, hipStream_t st);
-void launch_finish_equaliser_cx(const Lay& l, float* ws, float* g_k1, float* g_k2, hipStream_t st);
+void launch_chain_equaliser_cx(const Lay& l, float* ws, float* g_k1, float* g_k2, hipStream_t st);
 
 // v2vae_fit_rs.hip: whole fit loop on chip for small real shapes; 1 = launched, 0 = shape not covered, < 0 = error
 int launch_fit_rs(const Lay& l, const v2vae_fit_args* a, const int64_t n[5], hipStream_t st);
