@@ -151,6 +151,9 @@ typedef struct v2vae_train_args {
     int64_t step;         /* 1-based Adam step count */
     int32_t learn_scaling;   /* 0: the scaling section is not updated (lib/real_equalization.py:1014-1037) */
     int32_t adaptive_noise;  /* lib/real_equalization.py:921-923 */
+    int32_t freeze_h2;       /* 1: the second-order channel kernel is not updated; with h2 = 0 and unit scaling this is the
+                                linear-channel VAE of lib/real_equalization.py:564-690 (same ELBO, :629-664) */
+    int32_t reserved;
 } v2vae_train_args;
 
 /* One whole single-GPU training step of GenericTorchBlindEqualizer.fit's loop body
@@ -183,6 +186,7 @@ typedef struct v2vae_fit_args {
     int32_t n_batches;
     int32_t learn_scaling;
     int32_t adaptive_noise;
+    int32_t freeze_h2;        /* as in v2vae_train_args */
 } v2vae_fit_args;
 
 /* Host-side helper (no GPU work): per-step Adam constants of v2vae_adam_amsgrad for steps

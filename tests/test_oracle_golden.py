@@ -128,3 +128,43 @@ def test_adam_amsgrad_reference_matches_torch():
         opt.step()
         pn, m, v, vm = orc.adam_amsgrad_reference(pn, gnp, m, v, vm, step, 3e-3)
         assert np.allclose(pn, p.detach().numpy(), rtol=1e-12, atol=1e-14)
+
+
+LIN_STEP_CASES = [f"{n}_{t}" for n in ("linvae", "svvae", "svvae_L8S1") for t in ("f64", "f32")]
+
+
+@pytest.mark.parametrize("name", LIN_STEP_CASES)
+def test_linear_channel_elbo_matches_reference(name):
+    """The reference's linear-channel VAEs (LinearVAE, SecondVolterraVAE): the direct restatement of their ELBO and the
+    second-order ELBO with h2 = 0 and unit scaling (what the kernels run for them) both reproduce the reference."""
+    g = np.load(os.path.join(GOLDEN, f"vae_real_step_{name}.npz"))
+    dt = _dt(name)
+    tol = 1e-9 if dt == torch.float64 else 2e-4
+    y = torch.from_numpy(g["rx"]).to(dt)
+    h = torch.from_numpy(g["h"]).to(dt).requires_grad_(True)
+    lv = torch.from_numpy(g["constellation"]).to(dt)
+    prior = torch.ones_like(lv) / len(lv)
+    nv = torch.tensor(float(g["noise_variance_in"]), dtype=dt)
+    S = int(g["S"])
+    if str(g["kind"]) == "linvae":
+        k1 = torch.from_numpy(g["eq_w"].reshape(-1)).to(dt).requires_grad_(True)
+        xhat = orc.fir_equaliser(y, k1, S)
+        eq = [(k1, g["g_eq_w"].reshape(-1))]
+    else:
+        k1 = torch.from_numpy(g["k1"]).to(dt).requires_grad_(True)
+        k2 = torch.from_numpy(g["k2"]).to(dt).requires_grad_(True)
+        xhat = orc.volterra_equaliser(y, k1, k2, S)
+        eq = [(k1, g["g_k1"]), (k2, g["g_k2"])]
+    assert _rel(xhat.detach(), g["xhat"]) < tol
+    loss, E, _ = orc.linear_channel_elbo(xhat, y, h, lv, prior, nv, S)
+    assert abs(float(loss.detach()) - float(g["loss"])) < tol * abs(float(g["loss"]))
+    W = len(g["rx"]) - int(g["L"]) + 1
+    assert abs(float(E.detach()) / W - float(g["noise_variance_out"])) < tol * float(g["noise_variance_out"])
+    loss.backward()
+    assert _rel(h.grad, g["g_h"]) < 10 * tol
+    for p, ref in eq:
+        assert _rel(p.grad, ref) < 10 * tol
+    # the second-order ELBO collapses to it
+    h2 = torch.zeros(len(g["h"]), len(g["h"]), dtype=dt)
+    loss2, E2, _ = orc.elbo_reference_form(xhat.detach(), y, h.detach(), h2, lv, prior, nv, torch.ones_like(lv), S)
+    assert abs(float(loss2) - float(loss.detach())) < max(tol, 1e-12) * abs(float(loss.detach()))

@@ -760,7 +760,7 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
 #pragma unroll
             for (int q = 0; q < RS_APT; ++q) {
                 const int idx = tid + q * RS_NT;
-                if (idx < nadam) {
+                if (idx < nadam && !(a.freeze_h2 && idx >= n0 && idx < n0 + n1)) {
                     const float gi = s_grad[idx];
                     const float mi = fmaf(w1, gi - am[q], am[q]);
                     const float vi = fmaf(w2 * gi, gi, av[q] * a.beta2);

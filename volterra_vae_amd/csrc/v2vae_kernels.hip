@@ -1360,8 +1360,14 @@ __global__ __launch_bounds__(NT) void k_fit_persistent(Lay l, v2vae_fit_args a, 
         __syncthreads();
         d_chain_equaliser(one, l, ws, g + n0 + n1, n3 ? g + n0 + n1 + n2 : nullptr);
         __syncthreads();
-        d_adam(one, nadam, prm, g, am, av, avm, w1, a.beta2, w2, a.step_size[n], a.bc2_sqrt[n], a.eps, scal,
-               a.adaptive_noise ? nv : nullptr, a.loss_curve ? a.loss_curve + (int64_t)m * a.n_batches + n : nullptr);
+        int64_t first = 0;
+        if (a.freeze_h2) {
+            d_adam(one, n0, prm, g, am, av, avm, w1, a.beta2, w2, a.step_size[n], a.bc2_sqrt[n], a.eps, nullptr, nullptr, nullptr);
+            first = n0 + n1;
+        }
+        d_adam(one, nadam - first, prm + first, g + first, am + first, av + first, avm + first, w1, a.beta2, w2, a.step_size[n],
+               a.bc2_sqrt[n], a.eps, scal, a.adaptive_noise ? nv : nullptr,
+               a.loss_curve ? a.loss_curve + (int64_t)m * a.n_batches + n : nullptr);
         if (a.y_eq) {
             const int64_t tot = (int64_t)a.n_batches * B;
             for (int idx = threadIdx.x; idx < l.ns * B; idx += NT) {
@@ -1651,8 +1657,15 @@ int v2vae_train_step(const v2vae_problem* p, const v2vae_train_args* a, void* st
     if ((rc = v2vae_finish_grads(p, a->ws, a->scal, nullptr, 7, g, g + n[0], g + n[0] + n[1], n[3] ? g + n[0] + n[1] + n[2] : nullptr,
                                  g + n[0] + n[1] + n[2] + n[3], stream))) return rc;
     const int64_t nadam = n[0] + n[1] + n[2] + n[3] + (a->learn_scaling ? n[4] : 0);
-    return v2vae_adam_amsgrad(nadam, a->params, g, a->adam_m, a->adam_v, a->adam_vmax, a->lr, a->beta1, a->beta2, a->eps,
-                              a->step, a->scal, a->adaptive_noise ? a->noise_var : nullptr, a->loss_out, stream);
+    int64_t first = 0;
+    if (a->freeze_h2) {  // update [h1] and [k1 | k2 | scaling] only
+        if ((rc = v2vae_adam_amsgrad(n[0], a->params, g, a->adam_m, a->adam_v, a->adam_vmax, a->lr, a->beta1, a->beta2, a->eps,
+                                     a->step, nullptr, nullptr, nullptr, stream))) return rc;
+        first = n[0] + n[1];
+    }
+    return v2vae_adam_amsgrad(nadam - first, a->params + first, g + first, a->adam_m + first, a->adam_v + first,
+                              a->adam_vmax + first, a->lr, a->beta1, a->beta2, a->eps, a->step, a->scal,
+                              a->adaptive_noise ? a->noise_var : nullptr, a->loss_out, stream);
 }
 
 int v2vae_adam_schedule(int64_t step0, int64_t n, const float* lr, float beta1, float beta2, float* step_size,

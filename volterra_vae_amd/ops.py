@@ -109,7 +109,7 @@ class Plan:
 
     # --- whole fused step ------------------------------------------------------------------
     def train_step(self, *, y, levels, prior, params, grads, adam_m, adam_v, adam_vmax, noise_var, xhat, loss_out,
-                   lr, step, beta1=0.9, beta2=0.999, eps=1e-8, learn_scaling=True, adaptive_noise=True):
+                   lr, step, beta1=0.9, beta2=0.999, eps=1e-8, learn_scaling=True, adaptive_noise=True, freeze_h2=False):
         a = TrainArgs()
         a.y, a.levels, a.prior = y.data_ptr(), levels.data_ptr(), prior.data_ptr()
         a.params, a.grads = params.data_ptr(), grads.data_ptr()
@@ -118,7 +118,7 @@ class Plan:
         a.xhat, a.gxhat = xhat.data_ptr(), self.gxhat.data_ptr()
         a.loss_out = 0 if loss_out is None else loss_out.data_ptr()
         a.lr, a.beta1, a.beta2, a.eps, a.step = lr, beta1, beta2, eps, step
-        a.learn_scaling, a.adaptive_noise = int(learn_scaling), int(adaptive_noise)
+        a.learn_scaling, a.adaptive_noise, a.freeze_h2 = int(learn_scaling), int(adaptive_noise), int(freeze_h2)
         check(lib.v2vae_train_step(C.byref(self.p), C.byref(a), _stream()), "v2vae_train_step")
 
 
@@ -164,7 +164,8 @@ class PersistentFit:
         self.gxhat = torch.zeros_like(self.xhat)
 
     def run(self, *, y, levels, prior, params, grads, adam_m, adam_v, adam_vmax, noise_var, lrs, step0=0,
-            y_eq=None, loss_curve=None, beta1=0.9, beta2=0.999, eps=1e-8, learn_scaling=True, adaptive_noise=True):
+            y_eq=None, loss_curve=None, beta1=0.9, beta2=0.999, eps=1e-8, learn_scaling=True, adaptive_noise=True,
+            freeze_h2=False):
         """y: [ns, T] (shared by all models) or [n_models, ns, T], T >= n_batches * B * sps; lrs: one learning
         rate per batch (its length is the number of batches); params & co: [n_models, pack]."""
         nb = len(lrs)
@@ -201,7 +202,7 @@ class PersistentFit:
         a.step_size, a.bc2_sqrt = sched[0].data_ptr(), sched[1].data_ptr()
         a.beta1, a.beta2, a.eps = beta1, beta2, eps
         a.n_models, a.n_batches = self.n_models, nb
-        a.learn_scaling, a.adaptive_noise = int(learn_scaling), int(adaptive_noise)
+        a.learn_scaling, a.adaptive_noise, a.freeze_h2 = int(learn_scaling), int(adaptive_noise), int(freeze_h2)
         check(lib.v2vae_fit_persistent(C.byref(p), C.byref(a), _stream()), "v2vae_fit_persistent")
         self._keep = sched  # the launch is asynchronous: keep the schedule alive until the next call
 

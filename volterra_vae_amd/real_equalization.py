@@ -227,7 +227,7 @@ class VAESecondVolterraForward(GenericTorchBlindProbabilisticEqualizer):
         offsets = {}
         for g in groups:
             g["params"] = list(g["params"]) if not torch.is_tensor(g["params"]) else [g["params"]]
-        named = {"channel_h1": 0, "channel_h2": 1, "noise_scale": 4}
+        named = {"channel_h1": 0, "channel_filter": 0, "channel_h2": 1, "noise_scale": 4}
         for g in groups:
             if g["name"] == "equaliser":
                 s = self._sections[2][0]
@@ -293,6 +293,7 @@ class VAESecondVolterraForward(GenericTorchBlindProbabilisticEqualizer):
     # True: always one launch (the stage-by-stage persistent kernel for shapes the on-chip one does not cover; it is
     # bitwise equal to the per-batch sequence but slower for a single model).  False: always per batch.
     persistent_fit = None
+    _freeze_h2 = False  # True in the linear-channel classes: the second-order channel kernel stays at zero
 
     def _persistent(self, B):
         key = ("persistent", B)
@@ -337,7 +338,8 @@ class VAESecondVolterraForward(GenericTorchBlindProbabilisticEqualizer):
             pf.run(y=y.view(1, -1), levels=levels, prior=prior, params=self._pack.view(1, -1), grads=opt.flat_grad.view(1, -1),
                    adam_m=opt.exp_avg.view(1, -1), adam_v=opt.exp_avg_sq.view(1, -1), adam_vmax=opt.max_exp_avg_sq.view(1, -1),
                    noise_var=self._noise_var, lrs=lrs, step0=opt.step_count, y_eq=yq, loss_curve=losses[:n_batches].view(1, -1),
-                   learn_scaling=self.learnable_noise_scaling, adaptive_noise=self.adaptive_noise_variance)
+                   learn_scaling=self.learnable_noise_scaling, adaptive_noise=self.adaptive_noise_variance,
+                   freeze_h2=self._freeze_h2)
             opt.step_count += n_batches
             y_eq[:n_batches * B] = yq.view(-1)
             loss_curve = losses[:n_batches].cpu().numpy().astype(np.float64)
@@ -352,7 +354,8 @@ class VAESecondVolterraForward(GenericTorchBlindProbabilisticEqualizer):
             plan.train_step(y=ysl, levels=levels, prior=prior, params=self._pack, grads=opt.flat_grad, adam_m=opt.exp_avg,
                             adam_v=opt.exp_avg_sq, adam_vmax=opt.max_exp_avg_sq, noise_var=self._noise_var,
                             xhat=y_eq[n * B:(n + 1) * B], loss_out=losses[n:n + 1], lr=lr_now, step=opt.step_count,
-                            learn_scaling=self.learnable_noise_scaling, adaptive_noise=self.adaptive_noise_variance)
+                            learn_scaling=self.learnable_noise_scaling, adaptive_noise=self.adaptive_noise_variance,
+                            freeze_h2=self._freeze_h2)
             if n % self.loss_print_interval == 0:
                 lrprint = lr_schedule.get_last_lr()[-1] if self.lr_schedule else self.learning_rate
                 print(f"Batch {n}, Loss: {losses[n].item():.3f} (LR: {lrprint:.3e})")
@@ -463,3 +466,87 @@ class SecondVolterraV2VAENoNoiseScaling(VAESecondVolterraForward):
 
     def __repr__(self) -> str:
         return "SecondVolterraV2VAE(Beta=1.0)"
+
+
+class VAELinearForward(VAESecondVolterraForward):
+    """Blind VAE equaliser with a LINEAR channel model (lib/real_equalization.py:564-690).  Its ELBO (:629-664) is the
+    second-order one with the quadratic channel kernel identically zero and unit noise scaling, so it runs on the same
+    kernels with `channel_h2` frozen at zero; `channel_filter` is the first-order channel kernel."""
+    _freeze_h2 = True
+
+    def __init__(self, channel_n_taps, learning_rate, constellation: np.ndarray,
+                 samples_per_symbol, batch_size, dtype=torch.float32, noise_variance=1.0,
+                 adaptive_noise_variance=True, torch_device=None, lr_schedule='step', **equaliser_kwargs) -> None:
+        super().__init__(channel_memory=channel_n_taps, learning_rate=learning_rate, constellation=constellation,
+                         samples_per_symbol=samples_per_symbol, batch_size=batch_size, dtype=dtype,
+                         noise_variance=noise_variance, adaptive_noise_variance=adaptive_noise_variance,
+                         noise_scaling=False, torch_device=torch_device, lr_schedule=lr_schedule, **equaliser_kwargs)
+        self.channel_n_taps = channel_n_taps
+        self.channel_filter = self.channel_h1
+        self.channel_h2.requires_grad = False
+
+    def get_parameters(self):
+        return [{'params': self.channel_filter, 'name': 'channel_filter'},
+                {'params': self.equaliser.parameters(), 'name': 'equaliser'}]
+
+    def _update_model(self, loss):
+        loss.backward(retain_graph=True)
+        self.optimizer.step()
+        self.channel_filter.grad = None
+        self.equaliser.zero_grad()
+
+    def print_model_parameters(self):
+        print("Equaliser")
+        print(self.equaliser)
+        print(f"Channel: {self.channel_filter}")
+        print(f"Noise variance: {self.noise_variance}")
+
+    def train_mode(self):
+        self.channel_filter.requires_grad = True
+        self.equaliser.train()
+
+    def eval_mode(self):
+        self.channel_filter.requires_grad = False
+        self.equaliser.eval()
+
+
+class LinearVAE(VAELinearForward):
+    """Linear channel, linear (strided FIR) equaliser, lib/real_equalization.py:693-713."""
+
+    def _equaliser_sizes(self, **equaliser_kwargs):
+        return equaliser_kwargs['equaliser_n_taps'], 0
+
+    def initialize_equaliser(self, **equaliser_kwargs):
+        return StridedFIREqualiser(equaliser_kwargs['equaliser_n_taps'], self.samples_per_symbol, dtype=self.dtype,
+                                   torch_device=self.torch_device, _storage=self._eq_storage[0])
+
+    def forward(self, y):
+        return self.equaliser.forward(y[None, None, :]).squeeze()
+
+    def __repr__(self) -> str:
+        return "LinVAE"
+
+
+class SecondVolterraVAE(VAELinearForward):
+    """Linear channel, second-order Volterra equaliser, lib/real_equalization.py:716-736."""
+
+    def __init__(self, channel_memory, learning_rate, constellation: np.ndarray, samples_per_symbol,
+                 batch_size, dtype=torch.float32, noise_variance=1, adaptive_noise_variance=True,
+                 torch_device=None, lr_schedule='step', **equaliser_kwargs) -> None:
+        super().__init__(channel_memory, learning_rate, constellation, samples_per_symbol, batch_size, dtype,
+                         noise_variance, adaptive_noise_variance, torch_device, lr_schedule, **equaliser_kwargs)
+
+    def _equaliser_sizes(self, **equaliser_kwargs):
+        return equaliser_kwargs['equaliser_n_lags1'], equaliser_kwargs['equaliser_n_lags2']
+
+    def initialize_equaliser(self, **equaliser_kwargs):
+        return SecondOrderVolterraSeries(n_lags1=equaliser_kwargs['equaliser_n_lags1'],
+                                         n_lags2=equaliser_kwargs['equaliser_n_lags2'],
+                                         samples_per_symbol=self.samples_per_symbol,
+                                         dtype=self.dtype, torch_device=self.torch_device, _storage=self._eq_storage)
+
+    def forward(self, y):
+        return self.equaliser.forward(y)
+
+    def __repr__(self) -> str:
+        return "SecondVolterraVAE"
