@@ -1,0 +1,73 @@
+"""GPU tests that pin the COMPLEX kernels against the reference: its complex LinearVAE (lib/complex_equalization.py:746-916,
+linear channel + linear equaliser) is the complex V2VAE at h2 = 0 with unit noise scaling, so its golden vectors
+(tests/golden/make_golden_complex_linear.py) check the complex soft demapper, the complex equaliser kernels and the
+matrix-core ELBO kernel (forward value, gradients, Adam trajectory) on that subset of the model."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-5
+
+
+def rel(a, b):
+    a = np.asarray(a.detach().cpu() if torch.is_tensor(a) else a).reshape(-1)
+    b = np.asarray(b).reshape(-1)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def make(g, lr=5e-3):
+    from volterra_vae_amd.complex_equalization import LinearVAE
+    return LinearVAE(encoder_n_taps=int(g["L"]), learning_rate=lr, constellation=g["constellation"], samples_per_symbol=int(g["S"]),
+                     batch_size=int(g["B"]), noise_variance=float(g["noise_variance_in"]), torch_device=torch.device("cuda"),
+                     decoder_n_taps=int(g["l1"]))
+
+
+@pytest.mark.parametrize("case", ["L15S2", "L25S2", "L9S1"])
+@pytest.mark.parametrize("generic", [False, True])
+def test_single_step_against_reference(case, generic, monkeypatch):
+    if generic:
+        monkeypatch.setenv("V2VAE_FORCE_GENERIC", "1")
+    g32 = np.load(os.path.join(GOLDEN, f"vae_complex_step_{case}_f32.npz"))
+    g64 = np.load(os.path.join(GOLDEN, f"vae_complex_step_{case}_f64.npz"))
+    m = make(g32)
+    assert repr(m) == "LinVAE"
+    m.load_reference_weights(g32["enc_w"], g32["dec_w"])
+    assert rel(m.encoder_weight, g32["enc_w"]) == 0 and rel(m.decoder_weight, g32["dec_w"]) == 0
+    y = torch.from_numpy(m.to_real_stacked(g32["rx"])).float().cuda()
+    xhat = m.forward(y)
+    assert rel(xhat, g64["xhat"]) < TOL
+    q = m._soft_demapping(xhat)
+    assert rel(q, g64["q"]) < 1e-4
+    loss = m._calculate_loss(xhat, y)
+    assert abs(float(loss.detach()) - float(g64["loss"])) < TOL * abs(float(g64["loss"]))
+    assert abs(float(m.noise_variance) - float(g64["noise_variance_out"])) < TOL * float(g64["noise_variance_out"])
+    loss.backward()
+    # gradients in the reference's layout: h1 = flip(w0 + i w1), k1 = conj(w0 + i w1)
+    g_enc = torch.flip(m.channel_h1.grad, dims=(1,)).unsqueeze(0)
+    gk = m.equaliser_k1.grad
+    g_dec = torch.stack((gk[0], -gk[1])).unsqueeze(0)
+    for ours, key in ((g_enc, "g_enc_w"), (g_dec, "g_dec_w")):
+        own = rel(g32[key], g64[key])
+        assert rel(ours, g64[key]) < TOL + own, (key, rel(ours, g64[key]), own)
+
+
+def test_fit_trajectory_against_reference():
+    g32 = np.load(os.path.join(GOLDEN, "vae_complex_fit_L25S2_f32.npz"))
+    g64 = np.load(os.path.join(GOLDEN, "vae_complex_fit_L25S2_f64.npz"))
+    m = make(g32, lr=float(g32["lr"]))
+    y_eq = m.fit(g32["rx"])
+    assert np.iscomplexobj(y_eq) and y_eq.shape == g32["y_eq"].shape
+    assert float(m.channel_h2.abs().max()) == 0.0 and float((m.noise_scaling - 1).abs().max()) == 0.0
+
+    def chk(ours, key, tol):
+        own = rel(g32[key], g64[key])
+        assert rel(ours, g64[key]) < tol + own, (key, rel(ours, g64[key]), own)
+    chk(y_eq, "y_eq", TOL)
+    chk(m.encoder_weight, "enc_w", TOL)
+    chk(m.decoder_weight, "dec_w", TOL)
+    assert abs(float(m.noise_variance) - float(g64["noise_variance_out"])) < TOL * float(g64["noise_variance_out"])
+    chk(m.apply(g32["rx_val"]), "y_apply", TOL)

@@ -61,6 +61,7 @@ class GenericTorchBlindEqualizer(object):
 class VAESecondVolterraForward(GenericTorchBlindEqualizer):
     """Complex V2VAE parent class: second-order Volterra channel model, pluggable equaliser."""
     IS_PROBABILISTIC = True
+    _freeze_h2 = False  # True in the linear-channel class: the second-order channel kernel stays at zero
 
     def __init__(self, channel_memory, learning_rate, constellation: np.ndarray,
                  samples_per_symbol, batch_size, dtype=torch.float32, noise_variance=1.0,
@@ -102,7 +103,7 @@ class VAESecondVolterraForward(GenericTorchBlindEqualizer):
         self.learning_rate = learning_rate
         self.epsilon = 1e-12
         self._plans = {}
-        groups = [{'params': [self.channel_h1, self.channel_h2], 'name': 'channel'},
+        groups = [{'params': [self.channel_h1] + ([] if self._freeze_h2 else [self.channel_h2]), 'name': 'channel'},
                   {'params': [p for p in (self.equaliser_k1, self.equaliser_k2) if p is not None], 'name': 'equaliser'}]
         offsets = {id(self.channel_h1): self._sections[0], id(self.channel_h2): self._sections[1],
                    id(self.equaliser_k1): self._sections[2]}
@@ -114,7 +115,7 @@ class VAESecondVolterraForward(GenericTorchBlindEqualizer):
         self.optimizer = PackedAdamAMSGrad(groups, self._pack, offsets, lr=self.learning_rate)
 
     def _trainable(self):
-        ps = [self.channel_h1, self.channel_h2, self.equaliser_k1]
+        ps = [self.channel_h1, self.equaliser_k1] if self._freeze_h2 else [self.channel_h1, self.channel_h2, self.equaliser_k1]
         if self.equaliser_k2 is not None:
             ps.append(self.equaliser_k2)
         if self.learnable_noise_scaling:
@@ -199,7 +200,7 @@ class VAESecondVolterraForward(GenericTorchBlindEqualizer):
                             adam_m=opt.exp_avg, adam_v=opt.exp_avg_sq, adam_vmax=opt.max_exp_avg_sq,
                             noise_var=self._noise_var, xhat=xhat, loss_out=self.loss_curve[n:n + 1], lr=opt.current_lr(),
                             step=opt.step_count, learn_scaling=self.learnable_noise_scaling,
-                            adaptive_noise=self.adaptive_noise_variance)
+                            adaptive_noise=self.adaptive_noise_variance, freeze_h2=self._freeze_h2)
             if n % self.loss_print_interval == 0:
                 print(f"Batch {n}, Loss: {self.loss_curve[n].item():.3f}")
             y_eq[:, n * B:(n + 1) * B] = xhat
@@ -244,3 +245,61 @@ class LinearV2VAE(VAESecondVolterraForward):
 
     def __repr__(self) -> str:
         return "ComplexLinV2VAE"
+
+
+class LinearVAE(VAESecondVolterraForward):
+    """The reference's complex VAE with LINEAR channel model and linear equaliser (lib/complex_equalization.py:746-916) on the
+    same kernels: second-order channel kernel frozen at zero, unit noise scaling.
+
+    The reference stores both filters as Conv1d weights [1, 2, n] = (w0, w1) and applies them as cross-correlations,
+    the equaliser "pre-conjugated" (:908-913); in this package's conventions (convolution channel, plain-product
+    equaliser) that is   h1 = flip(w0 + i w1)   and   k1 = conj(w0 + i w1).   `encoder_weight` / `decoder_weight` give
+    the parameters in the reference's layout, `load_reference_weights` takes them."""
+    _freeze_h2 = True
+
+    def __init__(self, encoder_n_taps, learning_rate, constellation: np.ndarray, samples_per_symbol,
+                 batch_size, dtype=torch.float32, noise_variance=1, adaptive_noise_variance=True, torch_device=None,
+                 flex_update_interval=None, **decoder_kwargs) -> None:
+        super().__init__(channel_memory=encoder_n_taps, learning_rate=learning_rate, constellation=constellation,
+                         samples_per_symbol=samples_per_symbol, batch_size=batch_size, dtype=dtype,
+                         noise_variance=noise_variance, adaptive_noise_variance=adaptive_noise_variance, noise_scaling=False,
+                         torch_device=torch_device, flex_update_interval=flex_update_interval,
+                         equaliser_n_taps=decoder_kwargs['decoder_n_taps'])
+        self.encoder_n_taps = encoder_n_taps
+        # Dirac initialisation of the reference's correlation filter (:763) sits at tap n // 2 of w0, i.e. at the mirrored
+        # tap of the convolution kernel
+        with torch.no_grad():
+            self.channel_h1.zero_()
+            self.channel_h1[0, encoder_n_taps - 1 - encoder_n_taps // 2] = 1.0
+
+    def _equaliser_sizes(self, **equaliser_kwargs):
+        n = equaliser_kwargs['equaliser_n_taps']
+        assert (n + 1) % 2 == 0
+        return n, 0
+
+    @property
+    def encoder_weight(self):
+        return torch.flip(self.channel_h1.detach(), dims=(1,)).unsqueeze(0).clone()
+
+    @property
+    def decoder_weight(self):
+        k = self.equaliser_k1.detach()
+        return torch.stack((k[0], -k[1])).unsqueeze(0)
+
+    def load_reference_weights(self, encoder_weight=None, decoder_weight=None):
+        with torch.no_grad():
+            if encoder_weight is not None:
+                w = torch.as_tensor(encoder_weight, dtype=self.dtype, device=self.torch_device).reshape(2, -1)
+                self.channel_h1.copy_(torch.flip(w, dims=(1,)))
+            if decoder_weight is not None:
+                w = torch.as_tensor(decoder_weight, dtype=self.dtype, device=self.torch_device).reshape(2, -1)
+                self.equaliser_k1[0].copy_(w[0])
+                self.equaliser_k1[1].copy_(-w[1])
+
+    def print_model_parameters(self):
+        print(f"encoder: {self.encoder_weight}")
+        print(f"decoder: {self.decoder_weight}")
+        print(f"Noise variance: {self.noise_variance}")
+
+    def __repr__(self) -> str:
+        return "LinVAE"
