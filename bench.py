@@ -76,10 +76,15 @@ def sweep_main(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    backend = os.environ.get("V2VAE_BENCH_BACKEND", "nccl")
+    local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     n_total, L, S, l1, l2, B, C = 1024, 15, 2, 25, 25, 500, 4
     lo, hi = shard_models(rank, world, n_total)
     M = hi - lo
@@ -167,10 +172,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    backend = os.environ.get("V2VAE_BENCH_BACKEND", "nccl")  # "gloo": rehearsal of the multi-rank path on a one-GPU box
+    local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     L, S, l1, l2, order = 25, 2, 25, 25, 16
     M = int(round(np.sqrt(order)))
