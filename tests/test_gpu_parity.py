@@ -141,7 +141,36 @@ def test_complex_step_matches_oracle(L, S, l1, l2, B, M):
         assert rel(out["g"]["k2"], tk2.grad) < TOL
 
 
-def test_complex_L65_shape_runs_on_generic_kernels():
+@pytest.mark.parametrize("L,S,l1,l2,B,M", [(41, 2, 9, 5, 700, 4), (25, 1, 7, 5, 600, 4), (33, 1, 5, 3, 500, 2),
+                                           (65, 2, 9, 5, 1100, 4), (95, 2, 7, 0, 800, 4)])
+def test_complex_long_channel_blocked_kernel_matches_oracle(L, S, l1, l2, B, M):
+    """16 < active taps per phase <= 48: the blocked matrix-core ELBO kernel (2 or 3 blocks of 16 taps, both phase counts),
+    several tiles and a ragged last one, against the fp64 autograd oracle."""
+    from oracle import v2vae_oracle as orc
+    from volterra_vae_amd.ops import Plan
+    y, levels, prior, scaling, h1, h2, k1, k2 = _complex_inputs(8, L, S, l1, l2, B, M)
+    h2 *= 0.4
+    nv = 0.09
+    t = lambda a: torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    th1, th2, tk1, tsc = t(h1), t(h2), t(k1), t(scaling)
+    tk2 = t(k2) if k2 is not None else None
+    ty = torch.tensor(y)
+    xr = orc.complex_equaliser(ty, tk1[0], tk1[1], None if tk2 is None else tk2[0], None if tk2 is None else tk2[1], S)
+    loss, E, kl = orc.complex_v2vae_loss(xr, ty, th1[0], th1[1], th2[0], th2[1], torch.tensor(levels), torch.tensor(prior),
+                                         torch.tensor(nv, dtype=torch.float64), tsc, S)
+    loss.backward()
+    plan = Plan(ns=2, sps=S, l1=l1, pad1=l1 // 2, l2=l2, L=L, C_levels=M, n_glob=B * S, device="cuda")
+    out = run_step(plan, dev(y), dev(h1), dev(h2), dev(k1), None if k2 is None else dev(k2), dev(levels), dev(prior),
+                   dev(scaling), dev(np.array([nv])))
+    assert abs(out["loss"] - float(loss.detach())) < TOL * abs(float(loss.detach()))
+    assert abs(out["E"] - float(E.detach())) < TOL * abs(float(E.detach()))
+    assert rel(out["g"]["h1"], th1.grad) < TOL
+    assert rel(out["g"]["h2"], th2.grad) < TOL
+    assert rel(out["g"]["k1"], tk1.grad) < TOL
+    assert rel(out["g"]["sc"], tsc.grad) < TOL
+
+
+def test_complex_L65_shape_matches_oracle():
     """64-QAM, channel memory 65, 65 lags (the shape of the 8-GPU configuration) at a size the CPU oracle handles."""
     from oracle import v2vae_oracle as orc
     from volterra_vae_amd.ops import Plan

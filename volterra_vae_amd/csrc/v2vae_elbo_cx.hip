@@ -22,15 +22,11 @@
 // per-symbol gradient is completed inside the block and gathered without atomics.
 #include <hip/hip_runtime.h>
 
+#include "v2vae_cx_common.h"
 #include "v2vae_layout.h"
 
 namespace v2vae {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-__device__ __forceinline__ int cx_kk(int q, int h) { return (q & 3) + 8 * (q >> 2) + 4 * h; }
-
-#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 template <int S>
 __global__ __launch_bounds__(NT) void k_elbo_cx(Lay l, const float* __restrict__ y, float* __restrict__ ws) {
@@ -753,86 +749,67 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
     }
 }
 
-// Lagged products of s = v_a + v_b over the owned symbols: C[d] = sum_m s[m] s[m + d], d = 0..15.
-__device__ __forceinline__ float cx_s_at(const Lay& l, const float* __restrict__ mom, int64_t m) {
-    if (m < l.sym_lo || m >= l.sym_lo + l.sym_cnt) return 0.f;
-    return mom[(int64_t)1 * l.sym_cnt + (m - l.sym_lo)] + mom[(int64_t)5 * l.sym_cnt + (m - l.sym_lo)];
-}
-
 constexpr int PS_PER = 8;               // symbols per thread and tile
-constexpr int PS_TILE = NT * PS_PER;    // symbols per tile; the tile's s values plus 16 of halo are staged in LDS
+constexpr int PS_TILE = NT * PS_PER;    // symbols per tile; the tile's s values plus NLAG of halo are staged in LDS
 
+template <int NLAG>
 __global__ __launch_bounds__(NT) void k_psum_cx(Lay l, float* __restrict__ ws) {
-    __shared__ double red[NT / 64][16];
-    __shared__ float s_s[PS_TILE + 16];
+    __shared__ double red[NT / 64][NLAG];
+    __shared__ float s_s[PS_TILE + NLAG];
     const float* __restrict__ mom = ws + l.o_mom;
-    double acc[16];
+    double acc[NLAG];
 #pragma unroll
-    for (int d = 0; d < 16; ++d) acc[d] = 0.0;
+    for (int d = 0; d < NLAG; ++d) acc[d] = 0.0;
     const int64_t ntile = (l.own_cnt + PS_TILE - 1) / PS_TILE;
     for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
         const int64_t m0 = l.own_lo + tile * PS_TILE;
         __syncthreads();
-        for (int i = threadIdx.x; i < PS_TILE + 16; i += NT) s_s[i] = cx_s_at(l, mom, m0 + i);
+        for (int i = threadIdx.x; i < PS_TILE + NLAG; i += NT) s_s[i] = cx_s_at(l, mom, m0 + i);
         __syncthreads();
-        float part[16];
+        float part[NLAG];
 #pragma unroll
-        for (int d = 0; d < 16; ++d) part[d] = 0.f;
+        for (int d = 0; d < NLAG; ++d) part[d] = 0.f;
 #pragma unroll
         for (int q = 0; q < PS_PER; ++q) {
             const int i = threadIdx.x + q * NT;
             const float s0 = (m0 + i < l.own_lo + l.own_cnt) ? s_s[i] : 0.f;
 #pragma unroll
-            for (int d = 0; d < 16; ++d) part[d] = fmaf(s0, s_s[i + d], part[d]);
+            for (int d = 0; d < NLAG; ++d) part[d] = fmaf(s0, s_s[i + d], part[d]);
         }
 #pragma unroll
-        for (int d = 0; d < 16; ++d) acc[d] += (double)part[d];
+        for (int d = 0; d < NLAG; ++d) acc[d] += (double)part[d];
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int d = 0; d < 16; ++d) {
+    for (int d = 0; d < NLAG; ++d) {
         double v = d <= l.kmax ? acc[d] : 0.0;
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
         if (lane == 0) red[wv][d] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 16) {
+    if (threadIdx.x < NLAG) {
         double s = 0.0;
         for (int w = 0; w < NT / 64; ++w) s += red[w][threadIdx.x];
-        reinterpret_cast<double*>(ws + l.o_psum_part)[(size_t)blockIdx.x * 16 + threadIdx.x] = s;
+        reinterpret_cast<double*>(ws + l.o_psum_part)[(size_t)blockIdx.x * NLAG + threadIdx.x] = s;
     }
 }
 
-__global__ __launch_bounds__(NT) void k_psum_finish_cx(Lay l, float* __restrict__ ws) {
-    __shared__ double red[16][17];
-    const int d = threadIdx.x & 15, c = threadIdx.x >> 4;  // 16 lags x 16 chunks
+// totals over the blocks, fixed order: thread (lag d, chunk c) sums blocks c, c + nchunk, ...; then the chunks in order
+__global__ __launch_bounds__(NT) void k_psum_finish_cx(Lay l, float* __restrict__ ws, int nlag) {
+    __shared__ double red[NT];
+    const int nchunk = NT / nlag;
+    const int d = threadIdx.x % nlag, c = threadIdx.x / nlag;
     const double* part = reinterpret_cast<const double*>(ws + l.o_psum_part);
     double s = 0.0;
-    for (int b = c; b < l.nblk_psum; b += 16) s += part[(size_t)b * 16 + d];
-    red[c][d] = s;
+    if (c < nchunk)
+        for (int b = c; b < l.nblk_psum; b += nchunk) s += part[(size_t)b * nlag + d];
+    red[threadIdx.x] = s;
     __syncthreads();
-    if (threadIdx.x < 16) {
+    if (threadIdx.x < nlag) {
         double t = 0.0;
-        for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
+        for (int k = 0; k < nchunk; ++k) t += red[k * nlag + threadIdx.x];
         reinterpret_cast<double*>(ws + l.o_psum_tot)[threadIdx.x] = t;
     }
-}
-
-// sum over the owned, valid windows t of phase r of s[t + a] s[t + b]
-__device__ __forceinline__ float psum_value(const Lay& l, const float* __restrict__ ws, int r, int a, int b) {
-    const float* __restrict__ mom = ws + l.o_mom;
-    const int kk = a < b ? a : b, d = a < b ? b - a : a - b;
-    const int64_t lo = l.own_lo, hi = l.own_lo + l.own_cnt;
-    const int64_t Tr = (l.W - 1 - r >= 0) ? (l.W - 1 - r) / l.S + 1 : 0;
-    const int64_t br = hi < Tr ? hi : Tr;
-    if (br <= lo) return 0.f;
-    double v = reinterpret_cast<const double*>(ws + l.o_psum_tot)[d];
-    auto c = [&](int64_t m) { return (double)(cx_s_at(l, mom, m) * cx_s_at(l, mom, m + d)); };
-    for (int64_t m = lo; m < lo + kk; ++m) v -= c(m);
-    const int64_t last = br - 1 + kk;
-    if (last >= hi) { for (int64_t m = hi; m <= last; ++m) v += c(m); }
-    else { for (int64_t m = last + 1; m < hi; ++m) v -= c(m); }
-    return (float)v;
 }
 
 // raw gradients of the complex channel kernels from the per-phase totals
@@ -910,8 +887,13 @@ int launch_elbo_cx(const Lay& l, const float* y, float* ws, hipStream_t st) {
 
 // lagged products of s = v_a + v_b (needs only the moments, so it runs right after the soft demapper)
 void launch_psum_cx(const Lay& l, float* ws, hipStream_t st) {
-    hipLaunchKernelGGL(k_psum_cx, dim3(l.nblk_psum), dim3(NT), 0, st, l, ws);
-    hipLaunchKernelGGL(k_psum_finish_cx, dim3(1), dim3(NT), 0, st, l, ws);
+    if (l.use_cxb) {
+        hipLaunchKernelGGL(k_psum_cx<CX_MAXLAG>, dim3(l.nblk_psum), dim3(NT), 0, st, l, ws);
+        hipLaunchKernelGGL(k_psum_finish_cx, dim3(1), dim3(NT), 0, st, l, ws, CX_MAXLAG);
+    } else {
+        hipLaunchKernelGGL(k_psum_cx<16>, dim3(l.nblk_psum), dim3(NT), 0, st, l, ws);
+        hipLaunchKernelGGL(k_psum_finish_cx, dim3(1), dim3(NT), 0, st, l, ws, 16);
+    }
 }
 
 void launch_chain_channel_cx(const Lay& l, float* ws, const double* scal, const float* grad_scale, float* g_h1, float* g_h2,

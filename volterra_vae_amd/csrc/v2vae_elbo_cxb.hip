@@ -1,0 +1,519 @@
+// Fused ELBO forward + backward for the complex V2VAE with LONG channel memory on the f32 matrix cores:
+// 16 < Le <= 48 active taps per stream and phase (e.g. L = 65 at two samples per symbol: Le = 33), where the
+// window-by-kernel contraction is a genuine dense product.
+//
+// Same mathematics and orientation as the <= 16-tap kernel (v2vae_elbo_cx.hip: windows on the lanes, taps in the
+// accumulator registers), with the taps cut into NB blocks of 16:
+//     [P | Q](xb)   = sum_jb [mu_a | mu_b](jb) . [[Hr, Hi], [-Hi, Hr]](jb, xb)       16 MFMA 32x32x2 per block pair
+//     T(xb)         = sum_jb s(jb) . |H|^2(jb, xb)                                     8
+//     [HWa|HWb](xb) = sum_jb [alpha | beta](jb) . [[Hr, -Hi], [Hi, Hr]](jb, xb)       16
+//     dE/dHr(xb,jb) += rho^T mu_a + sigma^T mu_b,  dE/dHi(xb,jb) += sigma^T mu_a - rho^T mu_b
+//                                                                   4 x 8 MFMA 16x16x4 (4 accumulator registers each)
+// The NB^2 x 40 constant A-operand images (92 KB per phase at NB = 3) do not fit LDS next to the tiles; they stay in
+// global memory (L2-resident, every wave streams the same sequence) and are fetched ahead of the MFMA chains.
+// One workgroup = 4 waves, ONE per SIMD: the per-block register images of z, w, ... (6 x 8 x NB) and the NB^2 gradient
+// tiles need the full 512-register budget; the kernel is bound by its MFMA chains (504 per 32-window slab at NB = 3).
+#include <hip/hip_runtime.h>
+
+#include "v2vae_cx_common.h"
+#include "v2vae_layout.h"
+
+namespace v2vae {
+
+constexpr int CXB_NW = 4;
+constexpr int CXB_NT = CXB_NW * 64;
+constexpr int CXB_NU = CXB_TWB / 32;
+
+// compact tap k of phase r -> channel tap index or -1
+__device__ __forceinline__ int cxb_tap(const Lay& l, int r, int k) {
+    if (k >= l.LE) return -1;
+    const int i = r + l.L - 1 - k * l.S;
+    return (i >= 0 && i < l.L) ? i : -1;
+}
+
+// symmetrised complex second-order kernel on compact taps (a, b) of phase r: plane 0 = Re, 1 = Im
+__device__ __forceinline__ float cxb_H(const Lay& l, const float* __restrict__ h2, int r, int plane, int a, int b) {
+    const int ta = cxb_tap(l, r, a), tb = cxb_tap(l, r, b);
+    if (ta < 0 || tb < 0) return 0.f;
+    const float* hp = h2 + (size_t)plane * l.L * l.L;
+    return hp[ta * l.L + tb] + hp[tb * l.L + ta];
+}
+
+__global__ __launch_bounds__(NT) void k_prep_cxb(Lay l, const float* __restrict__ h1, const float* __restrict__ h2,
+                                                 float* __restrict__ ws) {
+    const int NB = l.cxb_nb, LEB = l.cxb_leb;
+    const int tid = blockIdx.x * NT + threadIdx.x, nth = gridDim.x * NT;
+    for (int idx = tid; idx < l.S * 2 * LEB * LEB; idx += nth) {
+        const int b = idx % LEB, a = (idx / LEB) % LEB, p = (idx / (LEB * LEB)) % 2, r = idx / (2 * LEB * LEB);
+        ws[l.o_cxbH + idx] = cxb_H(l, h2, r, p, a, b);
+    }
+    for (int idx = tid; idx < l.S * 4 * LEB; idx += nth) {
+        const int x = idx % LEB, q = (idx / LEB) % 4, r = idx / (4 * LEB);
+        const int t = cxb_tap(l, r, x);
+        float v = 0.f;
+        if (t >= 0) v = q == 0 ? h1[t] : q == 1 ? h1[l.L + t] : cxb_H(l, h2, r, q - 2, x, x);
+        ws[l.o_cxbc + idx] = v;
+    }
+    // A-operand images [r][xb][jb][40 steps][64 lanes]; row index (output) jj = lane & 31 -> (stream cjj, tap yjj of block xb),
+    // contraction slots as in the single-block kernel, taps of block jb
+    const int64_t total = (int64_t)l.S * NB * NB * 40 * 64;
+    for (int64_t idx = tid; idx < total; idx += nth) {
+        const int ln = (int)(idx & 63), s = (int)((idx >> 6) % 40);
+        const int pair = (int)((idx / (40 * 64)) % (NB * NB)), r = (int)(idx / ((int64_t)40 * 64 * NB * NB));
+        const int xb = pair / NB, jb = pair % NB;
+        const int jj = ln & 31, hh = ln >> 5, cjj = jj >> 4, yo = 16 * xb + (jj & 15);
+        float v;
+        if (s < 16) {          // [[Hr, Hi], [-Hi, Hr]], k = 2 s + h
+            const int k = 2 * s + hh, ck = k >> 4, xi = 16 * jb + (k & 15);
+            const float a = cxb_H(l, h2, r, 0, xi, yo), b = cxb_H(l, h2, r, 1, xi, yo);
+            v = ck == 0 ? (cjj == 0 ? a : b) : (cjj == 0 ? -b : a);
+        } else if (s < 24) {   // |H|^2, k = 2 (s - 16) + h
+            const int xi = 16 * jb + 2 * (s - 16) + hh;
+            const float a = cxb_H(l, h2, r, 0, yo, xi), b = cxb_H(l, h2, r, 1, yo, xi);
+            v = cjj == 0 ? a * a + b * b : 0.f;
+        } else {               // [[Hr, -Hi], [Hi, Hr]], k-slot <-> (stream (s - 24) >> 3, tap kk((s - 24) & 7, h))
+            const int s2 = s - 24, ck = s2 >> 3, xi = 16 * jb + cx_kk(s2 & 7, hh);
+            const float a = cxb_H(l, h2, r, 0, xi, yo), b = cxb_H(l, h2, r, 1, xi, yo);
+            v = ck == 0 ? (cjj == 0 ? a : -b) : (cjj == 0 ? b : a);
+        }
+        ws[l.o_cxbA + idx] = v;
+    }
+}
+
+template <int S, int NB>
+__global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restrict__ y, float* __restrict__ ws) {
+    extern __shared__ __align__(16) float sm[];
+    constexpr int TWB = CXB_TWB, NU = CXB_NU, TP = CX_TP, NW = CXB_NW;
+    constexpr int LEB = 16 * NB, MS = TWB + LEB + 16, NSIG = 32 + LEB, NWP = NW / S;
+    constexpr int REC = 2 * LEB * LEB + 4 * LEB;
+    constexpr int STG = 11 * MS + 2 * S * TWB;
+    constexpr int ADB = 16 + 16 * 48;
+    float* s_stage = sm;                       // moments float4 [2][MS] | means [2][MS] | s [MS] | y' [2][S][TWB]
+    float* s_c = s_stage + STG;                // [S][4][LEB]  h1r, h1i, diag Hr, diag Hi
+    float* s_T = s_c + S * 4 * LEB;            // [NW][32 * TP]  transposing buffer of rho / sigma
+    float* s_B = s_T + NW * 32 * TP;           // [NW][2][ADB]   anti-diagonal buffers (zero padded)
+    float* s_P = s_B + NW * 2 * ADB;           // [S][NU][6][NSIG] anti-diagonal partial sums
+    float* s_rec = s_P + S * NU * 6 * NSIG;    // [S][REC]
+    __shared__ double dred[NW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int r = wv / NWP, wsub = wv % NWP;
+    float* Tb = s_T + wv * 32 * TP;
+    float* Bd0 = s_B + wv * 2 * ADB + 16;
+    float* Bd1 = Bd0 + ADB;
+    const float* __restrict__ mom = ws + l.o_mom;
+    float* __restrict__ gmom = ws + l.o_gmom;
+    const int64_t own_hi = l.own_lo + l.own_cnt, sym_hi = l.sym_lo + l.sym_cnt;
+    const int TS = TWB - l.kmax;
+
+    for (int idx = tid; idx < S * 4 * LEB; idx += CXB_NT) s_c[idx] = ws[l.o_cxbc + idx];
+    for (int idx = tid; idx < NW * 2 * ADB; idx += CXB_NT) s_B[idx] = 0.f;
+    for (int idx = tid; idx < S * REC; idx += CXB_NT) s_rec[idx] = 0.f;
+    const float* __restrict__ Abase = ws + l.o_cxbA + (size_t)r * NB * NB * 40 * 64 + lane;
+    const float* cst = s_c + r * 4 * LEB;
+    __syncthreads();
+    float dd_sum[S];
+#pragma unroll
+    for (int rr = 0; rr < S; ++rr) {
+        float t = 0.f;
+        for (int kk = 0; kk < l.LE; ++kk) {
+            const float dr = s_c[(rr * 4 + 2) * LEB + kk], di = s_c[(rr * 4 + 3) * LEB + kk];
+            t += dr * dr + di * di;
+        }
+        dd_sum[rr] = t;
+    }
+
+    f32x4 Gr[NB][NB], Gi[NB][NB];
+    float ghr[NB][8], ghi[NB][8], gdr[NB][8], gdi[NB][8];
+#pragma unroll
+    for (int a = 0; a < NB; ++a) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { Gr[a][b][g] = 0.f; Gi[a][b][g] = 0.f; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { ghr[a][q] = 0.f; ghi[a][q] = 0.f; gdr[a][q] = 0.f; gdi[a][q] = 0.f; }
+    }
+    double Eacc = 0.0;
+
+    // staging of one block tile through registers: the loads of tile n + 1 are in flight while tile n is computed
+    constexpr int NSL = (MS + CXB_NT - 1) / CXB_NT;
+    constexpr int NYW = (2 * S * TWB + CXB_NT - 1) / CXB_NT;
+    float4 prea[NSL], preb[NSL];
+    float prey[NYW];
+    auto stage_load = [&](int tile) {
+        const int64_t s0 = l.own_lo + (int64_t)tile * TS;
+        const int64_t s1 = (s0 + TS < own_hi) ? s0 + TS : own_hi;
+        const int64_t tbase = s0 - l.kmax;
+#pragma unroll
+        for (int u = 0; u < NSL; ++u) {
+            const int ms = tid + u * CXB_NT;
+            const int64_t m = tbase + ms;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+            if (ms < MS && m >= l.sym_lo && m < sym_hi) {
+                const float* g = mom + (m - l.sym_lo);
+                const int64_t st = l.sym_cnt;
+                a = make_float4(g[0], g[st], g[2 * st], g[3 * st]);
+                b = make_float4(g[4 * st], g[5 * st], g[6 * st], g[7 * st]);
+            }
+            prea[u] = a; preb[u] = b;
+        }
+#pragma unroll
+        for (int u = 0; u < NYW; ++u) {
+            const int e = tid + u * CXB_NT;
+            const int o = e / (S * TWB), rem = e - o * S * TWB;
+            const int rr = rem / TWB, slot = rem - rr * TWB;
+            const int64_t t = tbase + slot, n = t * S + rr;
+            float v = 0.f;
+            if (e < 2 * S * TWB && t < s1 && n >= 0 && n < l.W) {
+                const int64_t loc = l.pre + n - l.y_lo;
+                if (loc >= 0 && loc < l.y_len) v = y[(int64_t)o * l.y_stride + loc];
+            }
+            prey[u] = v;
+        }
+    };
+    auto stage_store = [&](float* dst) {
+        float4* d4 = reinterpret_cast<float4*>(dst);
+#pragma unroll
+        for (int u = 0; u < NSL; ++u) {
+            const int ms = tid + u * CXB_NT;
+            if (ms < MS) {
+                d4[ms] = prea[u];
+                d4[MS + ms] = preb[u];
+                dst[8 * MS + ms] = prea[u].x;
+                dst[9 * MS + ms] = preb[u].x;
+                dst[10 * MS + ms] = prea[u].y + preb[u].y;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NYW; ++u) {
+            const int e = tid + u * CXB_NT;
+            if (e < 2 * S * TWB) dst[11 * MS + e] = prey[u];
+        }
+    };
+    if ((int)blockIdx.x < l.ntile_cxb) { stage_load(blockIdx.x); stage_store(s_stage); }
+    __syncthreads();
+
+    for (int tile = blockIdx.x; tile < l.ntile_cxb; tile += gridDim.x) {
+        const int64_t s0 = l.own_lo + (int64_t)tile * TS;
+        const int64_t s1 = (s0 + TS < own_hi) ? s0 + TS : own_hi;
+        const int64_t tbase = s0 - l.kmax;
+        const float4* s_m4 = reinterpret_cast<const float4*>(s_stage);   // [2][MS]
+        const float* s_mu = s_stage + 8 * MS;                             // [2][MS]
+        const float* s_S = s_mu + 2 * MS;
+        const float* s_yw = s_S + MS;
+        const bool more = tile + (int)gridDim.x < l.ntile_cxb;
+        if (more) stage_load(tile + gridDim.x);
+
+        for (int sub = wsub; sub < NU; sub += NWP) {
+            const int tsl = sub * 32;
+            const int64_t t = tbase + tsl + i, n = t * S + r;
+            const bool valid = (t < s1) && n >= 0 && n < l.W;
+            const bool own = valid && t >= s0;
+            const float mv = valid ? 1.f : 0.f, mo = own ? 1.f : 0.f;
+            float* Pu = s_P + ((size_t)(r * NU + sub) * 6) * NSIG;
+            for (int e = lane; e < 6 * NSIG; e += 64) Pu[e] = 0.f;
+
+            // ---- pass A: per output block H X and (H.H) s, then the per-(window, tap) algebra that does not need e
+            float zP[NB][8], zQ[NB][8], al[NB][8], be[NB][8], zz[NB][8], dvv[NB][8];
+            float a0 = 0.f, a1 = 0.f, q0 = 0.f, q1 = 0.f, sd0 = 0.f, sd1 = 0.f, vs = 0.f;
+#pragma unroll
+            for (int xb = 0; xb < NB; ++xb) {
+                f32x16 U, TT;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) { U[g] = 0.f; TT[g] = 0.f; }
+#pragma unroll
+                for (int jb = 0; jb < NB; ++jb) {
+                    const float* A = Abase + (size_t)(xb * NB + jb) * 40 * 64;
+                    float av[24];
+#pragma unroll
+                    for (int s = 0; s < 24; ++s) av[s] = A[s * 64];
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) {
+                        const int k = 2 * s + h;
+                        U = MFMA32(av[s], s_mu[(k >> 4) * MS + tsl + i + 16 * jb + (k & 15)], U);
+                    }
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) TT = MFMA32(av[16 + s], s_S[tsl + i + 16 * jb + 2 * s + h], TT);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int x = 16 * xb + cx_kk(q, h);
+                    const int slot = tsl + i + x;
+                    const float P = U[q], Q = U[q + 8], T = TT[q];
+                    const float4 m4a = s_m4[slot], m4b = s_m4[MS + slot];
+                    const float ma = m4a.x, va = m4a.y, ka = m4a.z, ga = m4a.w;
+                    const float mb = m4b.x, vb = m4b.y, kb = m4b.z, gb = m4b.w;
+                    const float hr = cst[x], hi = cst[LEB + x], dr = cst[2 * LEB + x], di = cst[3 * LEB + x];
+                    const float zp = fmaf(2.f, P, hr), zq = fmaf(2.f, Q, hi);
+                    a0 += hr * ma - hi * mb;
+                    a1 += hi * ma + hr * mb;
+                    q0 += ma * P - mb * Q;
+                    q1 += ma * Q + mb * P;
+                    const float Sv = va + vb, dv = va - vb, gs = ga + gb;
+                    sd0 = fmaf(dv, dr, sd0);
+                    sd1 = fmaf(dv, di, sd1);
+                    const float z2 = zp * zp + zq * zq;
+                    const float ca = dr * zp + di * zq, cb = dr * zq - di * zp;
+                    vs += Sv * z2 + 2.f * Sv * T + 2.f * (ka * ca + kb * cb) + gs * (dr * dr + di * di);
+                    al[xb][q] = 2.f * Sv * zp + 2.f * (ka * dr - kb * di);
+                    be[xb][q] = 2.f * Sv * zq + 2.f * (ka * di + kb * dr);
+                    zP[xb][q] = zp; zQ[xb][q] = zq;
+                    zz[xb][q] = z2 + 4.f * T;
+                    dvv[xb][q] = dv;
+                    gdr[xb][q] += mo * (2.f * (ka * zp + kb * zq) + 2.f * gs * dr);
+                    gdi[xb][q] += mo * (2.f * (ka * zq - kb * zp) + 2.f * gs * di);
+                }
+            }
+            a0 += __shfl_xor(a0, 32); a1 += __shfl_xor(a1, 32);
+            q0 += __shfl_xor(q0, 32); q1 += __shfl_xor(q1, 32);
+            sd0 += __shfl_xor(sd0, 32); sd1 += __shfl_xor(sd1, 32);
+            vs += __shfl_xor(vs, 32);
+            const float y0 = s_yw[(0 * S + r) * TWB + tsl + i], y1 = s_yw[(1 * S + r) * TWB + tsl + i];
+            float e0 = a0 + q0 + sd0 - y0, e1 = a1 + q1 + sd1 - y1;
+            if (own && h == 0) Eacc += (double)(e0 * e0 + e1 * e1 + vs);
+            e0 *= mv; e1 *= mv;
+
+            // ---- pass B: per output block H w, the anti-diagonal sums of the moment gradients, dE/dH
+#pragma unroll
+            for (int xb = 0; xb < NB; ++xb) {
+                f32x16 HW;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) HW[g] = 0.f;
+#pragma unroll
+                for (int jb = 0; jb < NB; ++jb) {
+                    const float* A = Abase + ((size_t)(xb * NB + jb) * 40 + 24) * 64;
+                    float av[16];
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) av[s] = A[s * 64];
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) HW = MFMA32(av[s], s < 8 ? al[jb][s & 7] : be[jb][s & 7], HW);
+                }
+                // anti-diagonal sums (symbol = window + tap), one pair of quantities per round through the wave's
+                // zero-padded buffers; LDS instructions of one wave execute in program order
+#pragma unroll
+                for (int round = 0; round < 3; ++round) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int xl = cx_kk(q, h), x = 16 * xb + xl;
+                        const float zp = zP[xb][q], zq = zQ[xb][q], dr = cst[2 * LEB + x], di = cst[3 * LEB + x];
+                        float da, db;
+                        if (round == 0) {
+                            da = 2.f * (e0 * zp + e1 * zq) + 2.f * HW[q];
+                            db = 2.f * (e1 * zp - e0 * zq) + 2.f * HW[q + 8];
+                        } else if (round == 1) {
+                            const float ed = 2.f * (e0 * dr + e1 * di);
+                            da = zz[xb][q] + ed;
+                            db = zz[xb][q] - ed;
+                        } else {
+                            da = 2.f * (dr * zp + di * zq);
+                            db = 2.f * (dr * zq - di * zp);
+                        }
+                        Bd0[xl * 48 + i] = mv * da;
+                        Bd1[xl * 48 + i] = mv * db;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < 48) {
+                        float sa = 0.f, sb = 0.f;
+#pragma unroll
+                        for (int x = 0; x < 16; ++x) {   // row x, window lane - x
+                            sa += Bd0[x * 47 + lane];
+                            sb += Bd1[x * 47 + lane];
+                        }
+                        Pu[(2 * round + 0) * NSIG + 16 * xb + lane] += sa;
+                        Pu[(2 * round + 1) * NSIG + 16 * xb + lane] += sb;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                // rho / sigma of this block (transposed through LDS), vector gradients
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int xl = cx_kk(q, h);
+                    const int slot = tsl + i + 16 * xb + xl;
+                    const float ma = s_mu[slot], mb = s_mu[MS + slot];
+                    const float gr = 2.f * (e0 * ma + e1 * mb), gi = 2.f * (e1 * ma - e0 * mb);
+                    ghr[xb][q] += mo * (gr + al[xb][q]);
+                    ghi[xb][q] += mo * (gi + be[xb][q]);
+                    gdr[xb][q] += mo * 2.f * e0 * dvv[xb][q];
+                    gdi[xb][q] += mo * 2.f * e1 * dvv[xb][q];
+                    Tb[i * TP + xl] = mo * (gr + 2.f * al[xb][q]);
+                    Tb[i * TP + 16 + xl] = mo * (gi + 2.f * be[xb][q]);
+                }
+                __builtin_amdgcn_wave_barrier();
+                {
+                    const int xa = lane & 15, kq = lane >> 4;
+                    float ar[8], as[8];
+#pragma unroll
+                    for (int st = 0; st < 8; ++st) {
+                        ar[st] = Tb[(4 * st + kq) * TP + xa];
+                        as[st] = Tb[(4 * st + kq) * TP + 16 + xa];
+                    }
+#pragma unroll
+                    for (int jb = 0; jb < NB; ++jb) {
+#pragma unroll
+                        for (int st = 0; st < 8; ++st) {
+                            const int w = tsl + 4 * st + kq + 16 * jb + xa;
+                            const float ma = s_mu[w], mb = s_mu[MS + w];
+                            Gr[xb][jb] = MFMA16(ar[st], ma, Gr[xb][jb]);
+                            Gr[xb][jb] = MFMA16(as[st], mb, Gr[xb][jb]);
+                            Gi[xb][jb] = MFMA16(as[st], ma, Gi[xb][jb]);
+                            Gi[xb][jb] = MFMA16(-ar[st], mb, Gi[xb][jb]);
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+        if (more) stage_store(s_stage);
+        // ---- gather: symbol slot ms = kmax + ml collects the partials of every slab whose 32 + Le - 1 slots cover it
+        for (int idx = tid; idx < 2 * TS; idx += CXB_NT) {
+            const int c = idx / TS, ml = idx - c * TS;
+            const int64_t m = s0 + ml;
+            if (m < s1) {
+                const int ms = ml + l.kmax;
+                float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+                const bool interior = (m - l.kmax) >= 0 && (m * S + S - 1) < l.W;
+                for (int rr = 0; rr < S; ++rr) {
+                    for (int d = (NSIG - 1) / 32; d >= 0; --d) {
+                        const int sub = (ms >> 5) - d, sg = (ms & 31) + 32 * d;
+                        if (sub >= 0 && sub < NU && sg < NSIG) {
+                            const float* P = s_P + ((size_t)(rr * NU + sub) * 6) * NSIG + sg;
+                            g0 += P[(0 + c) * NSIG]; g1 += P[(2 + c) * NSIG]; g2 += P[(4 + c) * NSIG];
+                        }
+                    }
+                    if (interior) g3 += dd_sum[rr];
+                    else
+                        for (int kk = 0; kk < l.LE; ++kk) {
+                            const int64_t t = m - kk, n = t * S + rr;
+                            if (n >= 0 && n < l.W) {
+                                const float dr = s_c[(rr * 4 + 2) * LEB + kk], di = s_c[(rr * 4 + 3) * LEB + kk];
+                                g3 += dr * dr + di * di;
+                            }
+                        }
+                }
+                float* gp = gmom + (int64_t)c * 4 * l.sym_cnt + (m - l.sym_lo);
+                gp[0] = g0; gp[l.sym_cnt] = g1; gp[2 * l.sym_cnt] = g2; gp[3 * l.sym_cnt] = g3;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- one record per (block, phase): the waves of a phase add their tiles in a fixed order
+    float* img = s_rec + (size_t)r * REC;
+    for (int w = 0; w < NWP; ++w) {
+        if (wsub == w) {
+#pragma unroll
+            for (int xb = 0; xb < NB; ++xb) {
+#pragma unroll
+                for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int a = 16 * xb + 4 * (lane >> 4) + g, b = 16 * jb + (lane & 15);
+                        img[a * LEB + b] += Gr[xb][jb][g];
+                        img[(LEB + a) * LEB + b] += Gi[xb][jb][g];
+                    }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    float v0 = ghr[xb][q], v1 = ghi[xb][q], v2 = gdr[xb][q], v3 = gdi[xb][q];
+#pragma unroll
+                    for (int off = 1; off < 32; off <<= 1) {
+                        v0 += __shfl_xor(v0, off); v1 += __shfl_xor(v1, off);
+                        v2 += __shfl_xor(v2, off); v3 += __shfl_xor(v3, off);
+                    }
+                    if (i == 0) {
+                        const int x = 16 * xb + cx_kk(q, h);
+                        img[2 * LEB * LEB + 0 * LEB + x] += v0;
+                        img[2 * LEB * LEB + 1 * LEB + x] += v1;
+                        img[2 * LEB * LEB + 2 * LEB + x] += v2;
+                        img[2 * LEB * LEB + 3 * LEB + x] += v3;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float* rec = ws + l.o_part_cxb + (size_t)blockIdx.x * S * REC;
+    for (int e = tid; e < S * REC; e += CXB_NT) rec[e] = s_rec[e];
+    double v = Eacc;
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) dred[wv] = v;
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int w = 0; w < NW; ++w) s += dred[w];
+        reinterpret_cast<double*>(ws + l.o_Epart)[blockIdx.x] = s;
+    }
+}
+
+// raw gradients of the complex channel kernels from the per-phase totals
+__global__ __launch_bounds__(NT) void k_chain_channel_cxb(Lay l, const float* __restrict__ ws, const double* __restrict__ scal,
+                                                          const float* __restrict__ grad_scale, float* __restrict__ g_h1,
+                                                          float* __restrict__ g_h2) {
+    const float lam = (float)scal[V2VAE_SCAL_LAMBDA] * (grad_scale ? grad_scale[0] : 1.f);
+    const int L = l.L, n1 = 2 * L, n2 = 2 * L * L, LEB = l.cxb_leb;
+    auto compact = [&](int tap, int* r, int* x) {
+        int rr = (tap - (L - 1)) % l.S;
+        if (rr < 0) rr += l.S;
+        *r = rr;
+        *x = (rr + L - 1 - tap) / l.S;
+    };
+    for (int idx = blockIdx.x * NT + threadIdx.x; idx < n1 + n2; idx += gridDim.x * NT) {
+        if (idx < n1) {
+            if (!g_h1) continue;
+            const int p = idx / L, tap = idx - p * L;
+            int r, x;
+            compact(tap, &r, &x);
+            g_h1[idx] = lam * ws[l.o_tot_cxb + (size_t)r * l.cxb_rec + 2 * LEB * LEB + p * LEB + x];
+        } else {
+            if (!g_h2) continue;
+            const int e = idx - n1;
+            const int p = e / (L * L), rem = e - p * L * L;
+            const int ti = rem / L, tj = rem - ti * L;
+            int ri, xi, rj, xj;
+            compact(ti, &ri, &xi);
+            compact(tj, &rj, &xj);
+            float v = 0.f;
+            if (ri == rj) {
+                const float* tot = ws + l.o_tot_cxb + (size_t)ri * l.cxb_rec;
+                const float* Hp = ws + l.o_cxbH + (size_t)(ri * 2 + p) * LEB * LEB;
+                auto G = [&](int a, int b) {
+                    float g = tot[(p * LEB + a) * LEB + b] + 4.f * Hp[a * LEB + b] * psum_value(l, ws, ri, a, b);
+                    if (a == b) g += tot[2 * LEB * LEB + (2 + p) * LEB + a];
+                    return g;
+                };
+                v = G(xi, xj) + G(xj, xi);
+            }
+            g_h2[e] = lam * v;
+        }
+    }
+}
+
+void launch_prep_cxb(const Lay& l, const float* h1, const float* h2, float* ws, hipStream_t st) {
+    hipLaunchKernelGGL(k_prep_cxb, dim3(64), dim3(NT), 0, st, l, h1, h2, ws);
+}
+
+int launch_elbo_cxb(const Lay& l, const float* y, float* ws, hipStream_t st) {
+    const int lds = l.lds_cxb;
+#define V2VAE_LAUNCH_CXB(SS, NBB)                                                                                          \
+    do {                                                                                                                   \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_elbo_cxb<SS, NBB>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                lds) != hipSuccess)                                                                        \
+            return V2VAE_ELAUNCH;                                                                                          \
+        hipLaunchKernelGGL((k_elbo_cxb<SS, NBB>), dim3(l.nblk_cxb), dim3(CXB_NT), lds, st, l, y, ws);                       \
+    } while (0)
+    if (l.cxb_nb == 2) { if (l.S == 1) V2VAE_LAUNCH_CXB(1, 2); else V2VAE_LAUNCH_CXB(2, 2); }
+    else { if (l.S == 1) V2VAE_LAUNCH_CXB(1, 3); else V2VAE_LAUNCH_CXB(2, 3); }
+#undef V2VAE_LAUNCH_CXB
+    return V2VAE_OK;
+}
+
+void launch_chain_channel_cxb(const Lay& l, float* ws, const double* scal, const float* grad_scale, float* g_h1, float* g_h2,
+                              hipStream_t st) {
+    const int n = 2 * l.L + 2 * l.L * l.L;
+    hipLaunchKernelGGL(k_chain_channel_cxb, dim3((n + NT - 1) / NT), dim3(NT), 0, st, l, (const float*)ws, scal, grad_scale, g_h1,
+                       g_h2);
+}
+
+}  // namespace v2vae

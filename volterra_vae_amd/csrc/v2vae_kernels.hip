@@ -84,7 +84,9 @@ int make_layout(const v2vae_problem* p, Lay* out) {
                      3 * (int64_t)l.LTp * tw + (int64_t)l.ns * 5 * NT + SCRATCH_F;
         if (fl * 4 <= LDS_BUDGET) { l.TWIN = tw; l.TS = ts; l.TSYM = tsym; l.lds_elbo = (int)(fl * 4); break; }
     }
-    if (l.TWIN == 0) return V2VAE_ESIZE;
+    // shapes beyond the generic ELBO kernel's tiling are still fine if a matrix-core kernel covers them (decided below)
+    int generic_elbo_ok = 1;
+    if (l.TWIN == 0) { generic_elbo_ok = 0; l.TWIN = 64; l.TS = 64 - l.kmax > 0 ? 64 - l.kmax : 1; l.TSYM = 64 + l.kmax + 4; l.lds_elbo = 0; }
     l.NG = NT / l.TWIN;
     l.ntile_elbo = (int)((l.own_cnt + l.TS - 1) / l.TS);
     l.nblk_elbo = l.ntile_elbo < MAX_BLOCKS ? l.ntile_elbo : MAX_BLOCKS;
@@ -94,9 +96,9 @@ int make_layout(const v2vae_problem* p, Lay* out) {
         l.nitems_elbo = l.nG_elbo + nb * nb;
         if (l.nitems_elbo <= NT) { l.nchunk_elbo = NT / l.nitems_elbo; l.maxi_elbo = 1; }
         else { l.nchunk_elbo = 1; l.maxi_elbo = (l.nitems_elbo + NT - 1) / NT; }
-        if (l.maxi_elbo > 4) return V2VAE_ESIZE;
+        if (l.maxi_elbo > 4) generic_elbo_ok = 0;
         if (l.nchunk_elbo > 16) l.nchunk_elbo = 16;
-        if (l.ns * l.LTp > NT) return V2VAE_ESIZE;
+        if (l.ns * l.LTp > NT) generic_elbo_ok = 0;
     }
     // ---- equaliser tiling
     l.ntile_eq = (int)((l.own_cnt + EQ_TB - 1) / EQ_TB);
@@ -133,7 +135,22 @@ int make_layout(const v2vae_problem* p, Lay* out) {
             l.lds_cx = ((11 * (256 + 48) + 2 * l.S * 256) + l.S * 40 * 64 + l.S * 64 + 8 * 32 * CX_TP + 8 * 2 * (16 + 16 * 48) + l.S * 8 * 6 * 64) * 4;
         else
             l.lds_cx = (8 * CX_MS + CX_MS + 2 * l.S * CX_TWB + l.S * 6 * 16 * CX_TWB + 4 * 32 * CX_TP) * 4;
-        l.nblk_E = l.use_cx ? l.nblk_cx : l.nblk_elbo;
+        // blocked variant for longer channels
+        l.use_cxb = (l.mode == 1 && l.LE > 16 && l.LE <= 48 && l.S <= 2 && getenv("V2VAE_FORCE_GENERIC") == nullptr) ? 1 : 0;
+        l.cxb_nb = (l.LE + 15) / 16;
+        l.cxb_leb = 16 * l.cxb_nb;
+        l.cxb_rec = 2 * l.cxb_leb * l.cxb_leb + 4 * l.cxb_leb;
+        {
+            const int tsb = CXB_TWB - l.kmax;
+            l.ntile_cxb = l.use_cxb ? (int)((l.own_cnt + tsb - 1) / tsb) : 0;
+            l.nblk_cxb = l.ntile_cxb < CX_BLOCKS ? l.ntile_cxb : CX_BLOCKS;
+            const int ms = CXB_TWB + l.cxb_leb + 16, nsig = 32 + l.cxb_leb;
+            l.lds_cxb = ((11 * ms + 2 * l.S * CXB_TWB) + l.S * 4 * l.cxb_leb + 4 * 32 * CX_TP + 4 * 2 * (16 + 16 * 48) +
+                         l.S * (CXB_TWB / 32) * 6 * nsig + l.S * l.cxb_rec) * 4;
+        }
+        l.nblk_E = l.use_cx ? l.nblk_cx : (l.use_cxb ? l.nblk_cxb : l.nblk_elbo);
+        if (!l.use_cx && !l.use_cxb && !generic_elbo_ok) return V2VAE_ESIZE;
+        l.generic_elbo_ok = generic_elbo_ok;
         int64_t nb = (l.own_cnt + NT - 1) / NT;
         l.nblk_psum = (int)(nb < 512 ? nb : 512);
     }
@@ -167,8 +184,13 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     l.o_cxh1 = take((int64_t)l.S * 2 * 16);
     l.o_part_cx = take(l.use_cx ? (int64_t)l.nblk_cx * l.S * CX_REC : 0);
     l.o_tot_cx = take((int64_t)l.S * CX_REC);
-    l.o_psum_part = take(2 * 16 * (int64_t)l.nblk_psum);
-    l.o_psum_tot = take(2 * 16);
+    l.o_psum_part = take(2 * CX_MAXLAG * (int64_t)l.nblk_psum);
+    l.o_psum_tot = take(2 * CX_MAXLAG);
+    l.o_cxbA = take(l.use_cxb ? (int64_t)l.S * l.cxb_nb * l.cxb_nb * 40 * 64 : 0);
+    l.o_cxbH = take(l.use_cxb ? (int64_t)l.S * 2 * l.cxb_leb * l.cxb_leb : 0);
+    l.o_cxbc = take(l.use_cxb ? (int64_t)l.S * 4 * l.cxb_leb : 0);
+    l.o_part_cxb = take(l.use_cxb ? (int64_t)l.nblk_cxb * l.S * l.cxb_rec : 0);
+    l.o_tot_cxb = take(l.use_cxb ? (int64_t)l.S * l.cxb_rec : 0);
     l.o_eqcxA = take(l.use_eqcx ? (int64_t)2 * l.eqcx_steps * 64 : 0);
     l.o_part_eqcx = take(l.use_eqcx ? (int64_t)l.nblk_eq * 4096 : 0);
     l.o_tot_eqcx = take(l.use_eqcx ? 4096 : 0);
@@ -177,11 +199,16 @@ int make_layout(const v2vae_problem* p, Lay* out) {
         if (l.rec_eq > mx) mx = l.rec_eq;
         if (l.rec_sym > mx) mx = l.rec_sym;
         if (l.S * CX_REC > mx) mx = l.S * CX_REC;
+        if (l.use_cxb && l.S * l.cxb_rec > mx) mx = l.S * l.cxb_rec;
         if (4096 > mx) mx = 4096;
         l.sumstage_stride = (int64_t)SUM_CHUNKS * mx;
         l.o_sumstage = take(3 * l.sumstage_stride);
     }
-    l.o_Epart = take(2 * (int64_t)(l.nblk_elbo > l.nblk_cx ? l.nblk_elbo : l.nblk_cx));
+    {
+        int nbE = l.nblk_elbo > l.nblk_cx ? l.nblk_elbo : l.nblk_cx;
+        if (l.nblk_cxb > nbE) nbE = l.nblk_cxb;
+        l.o_Epart = take(2 * (int64_t)nbE);
+    }
     l.o_KLpart = take(2 * (int64_t)l.nblk_sym);
     l.total_floats = o;
     *out = l;
@@ -1445,6 +1472,7 @@ int v2vae_prep_tables(const v2vae_problem* p, const float* h1, const float* h2, 
     if (!ws || (!h1 && !k1) || (h1 && !h2) || (k1 && l.l2 > 0 && !k2)) return V2VAE_EINVAL;
     hipLaunchKernelGGL(k_prep_tables, dim3(16), dim3(NT), 0, (hipStream_t)stream, l, h1, h2, k1, k2, (float*)ws);
     if (k1 && l.use_eqcx) launch_prep_eqcx(l, k1, k2, (float*)ws, (hipStream_t)stream);
+    if (h1 && l.use_cxb) launch_prep_cxb(l, h1, h2, (float*)ws, (hipStream_t)stream);
     return launch_status();
 }
 
@@ -1478,7 +1506,7 @@ int v2vae_demap_moments(const v2vae_problem* p, const float* xhat, const float* 
     else if (l.C <= 8) V2VAE_LAUNCH_DEMAP(8);
     else V2VAE_LAUNCH_DEMAP(16);
 #undef V2VAE_LAUNCH_DEMAP
-    if (l.use_cx && l.cx_gen == 2) launch_psum_cx(l, (float*)ws, (hipStream_t)stream);
+    if ((l.use_cx && l.cx_gen == 2) || l.use_cxb) launch_psum_cx(l, (float*)ws, (hipStream_t)stream);
     return launch_status();
 }
 
@@ -1500,6 +1528,10 @@ int v2vae_elbo_fused(const v2vae_problem* p, const float* y, void* ws, void* str
     hipStream_t st = (hipStream_t)stream;
     if (l.use_cx) {
         rc = launch_elbo_cx(l, y, (float*)ws, st);
+        return rc ? rc : launch_status();
+    }
+    if (l.use_cxb) {
+        rc = launch_elbo_cxb(l, y, (float*)ws, st);
         return rc ? rc : launch_status();
     }
 #define V2VAE_LAUNCH_ELBO(M)                                                                              \
@@ -1586,6 +1618,7 @@ int v2vae_finish_grads(const v2vae_problem* p, void* ws, const double* scal, con
     SumSets ss{};
     float* stage = w + l.o_sumstage;
     if ((which & 1) && l.use_cx) sum_sets_add(ss, w + l.o_part_cx, l.S * CX_REC, l.nblk_cx, stage, w + l.o_tot_cx);
+    else if ((which & 1) && l.use_cxb) sum_sets_add(ss, w + l.o_part_cxb, l.S * l.cxb_rec, l.nblk_cxb, stage, w + l.o_tot_cxb);
     else if (which & 1) sum_sets_add(ss, w + l.o_part_elbo, l.rec_elbo, l.nblk_elbo, stage, w + l.o_tot_elbo);
     if (which & 2) sum_sets_add(ss, w + l.o_part_sym, l.rec_sym, l.nblk_sym, stage + l.sumstage_stride, w + l.o_tot_sym);
     if ((which & 4) && l.use_eqcx) sum_sets_add(ss, w + l.o_part_eqcx, 4096, l.nblk_eq, stage + 2 * l.sumstage_stride, w + l.o_tot_eqcx);
@@ -1593,6 +1626,8 @@ int v2vae_finish_grads(const v2vae_problem* p, void* ws, const double* scal, con
     sum_sets_launch(ss, st);
     if ((which & 1) && l.use_cx) {
         launch_chain_channel_cx(l, w, scal, grad_scale, g_h1, g_h2, st);
+    } else if ((which & 1) && l.use_cxb) {
+        launch_chain_channel_cxb(l, w, scal, grad_scale, g_h1, g_h2, st);
     } else if (which & 1) {
         const int n = l.ns * l.L + l.ns * l.L * l.L;
         hipLaunchKernelGGL(k_chain_channel, dim3((n + NT - 1) / NT), dim3(NT), 0, st, l, (const float*)w, scal, grad_scale, g_h1, g_h2);
@@ -1691,7 +1726,7 @@ int v2vae_fit_persistent_kind(const v2vae_problem* p) {
     int64_t n[5];
     v2vae_pack_sizes(p, n);
     if (fit_rs_applicable(l, n[0] + n[1] + n[2] + n[3] + n[4])) return 2;
-    if (l.maxi_elbo != 1 || l.maxi_eq > 2) return V2VAE_ESIZE;
+    if (!l.generic_elbo_ok || l.maxi_elbo != 1 || l.maxi_eq > 2) return V2VAE_ESIZE;
     return 1;
 }
 
@@ -1717,8 +1752,9 @@ int v2vae_fit_persistent(const v2vae_problem* p, const v2vae_fit_args* a, void* 
         if (took < 0) return took;
         if (took == 1) return launch_status();
     }
-    if (l.maxi_elbo != 1 || l.maxi_eq > 2) return V2VAE_ESIZE;
+    if (!l.generic_elbo_ok || l.maxi_elbo != 1 || l.maxi_eq > 2) return V2VAE_ESIZE;
     l.use_cx = 0;
+    l.use_cxb = 0;
     l.use_eqcx = 0;
     l.nblk_E = l.nblk_elbo;
     const int lds = l.lds_elbo > l.lds_eq ? l.lds_elbo : l.lds_eq;

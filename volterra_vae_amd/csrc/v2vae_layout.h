@@ -29,6 +29,8 @@ constexpr int CX_TP = 33;            // row pitch of the per-wave transposing bu
 constexpr int CX_REC = 2112;         // floats per wave record: R 32x32, Ps 32x32, 4 vectors of 16
 constexpr int SUM_CHUNKS = 32;       // first-stage groups of the two-stage partial-record sums
 constexpr int CX_BLOCKS = 256;       // one workgroup per CU (the LDS image takes most of a CU)
+constexpr int CXB_TWB = 256;         // windows per phase per block tile of the blocked kernel
+constexpr int CX_MAXLAG = 48;        // lagged products kept for sum s s^T (largest blocked tap count)
 
 struct Lay {
     int ns, mode, S, l1, pad1, l2, L, C;
@@ -42,6 +44,7 @@ struct Lay {
     // ELBO tiling
     int TWIN, TS, NG, TSYM, ntile_elbo, nblk_elbo, nitems_elbo, nG_elbo, nchunk_elbo, maxi_elbo;
     int lds_elbo;            // bytes
+    int generic_elbo_ok;     // 0: the shape exceeds the generic ELBO kernel's tiling (only the matrix-core kernels cover it)
     // equaliser backward tiling
     int ntile_eq, nblk_eq, nitems_eq, nchunk_eq, maxi_eq, nk1;
     int lds_eq;              // bytes (forward and backward use the same carve)
@@ -50,6 +53,9 @@ struct Lay {
     int use_cx, cx_gen, cx_waves, ntile_cx, nblk_cx, lds_cx, nblk_E, nblk_psum;
     int64_t o_psum_part, o_psum_tot;
     int64_t o_cxH, o_cxh1, o_part_cx, o_tot_cx;
+    // blocked matrix-core ELBO path (complex, 16 < active taps per phase <= 48): taps in blocks of 16
+    int use_cxb, cxb_nb, cxb_leb, ntile_cxb, nblk_cxb, lds_cxb, cxb_rec;
+    int64_t o_cxbA, o_cxbH, o_cxbc, o_part_cxb, o_tot_cxb;
     // matrix-core equaliser path
     int use_eqcx, eqcx_lk, eqcx_steps;
     int64_t o_eqcxA, o_part_eqcx, o_tot_eqcx;
@@ -74,6 +80,12 @@ int launch_elbo_cx(const Lay& l, const float* y, float* ws, hipStream_t st);
 void launch_psum_cx(const Lay& l, float* ws, hipStream_t st);
 void launch_chain_channel_cx(const Lay& l, float* ws, const double* scal, const float* grad_scale, float* g_h1, float* g_h2,
                              hipStream_t st);
+
+// v2vae_elbo_cxb.hip
+void launch_prep_cxb(const Lay& l, const float* h1, const float* h2, float* ws, hipStream_t st);
+int launch_elbo_cxb(const Lay& l, const float* y, float* ws, hipStream_t st);
+void launch_chain_channel_cxb(const Lay& l, float* ws, const double* scal, const float* grad_scale, float* g_h1, float* g_h2,
+                              hipStream_t st);
 
 // two-stage deterministic sum of nrec records of `rec` floats: tot[e] = sum_b part[b][e]  (v2vae_kernels.hip)
 void launch_sum_records(const Lay& l, const float* part, int rec, int nrec, float* stage, float* tot, hipStream_t st);
