@@ -98,7 +98,9 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
-    const int r = wv / NWP, wsub = wv % NWP;
+    // wave-uniform by construction; saying so lets the table loads use scalar base + lane offset addressing (one 64-bit
+    // base per wave instead of one 64-bit address per lane and load)
+    const int r = __builtin_amdgcn_readfirstlane(wv / NWP), wsub = __builtin_amdgcn_readfirstlane(wv % NWP);
     float* Tb = s_T + wv * 32 * TP;
     float* Bd0 = s_B + wv * 2 * ADB + 16;
     float* Bd1 = Bd0 + ADB;
@@ -110,7 +112,8 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
     for (int idx = tid; idx < S * 4 * LEB; idx += CXB_NT) s_c[idx] = ws[l.o_cxbc + idx];
     for (int idx = tid; idx < NW * 2 * ADB; idx += CXB_NT) s_B[idx] = 0.f;
     for (int idx = tid; idx < S * REC; idx += CXB_NT) s_rec[idx] = 0.f;
-    const float* __restrict__ Abase = ws + l.o_cxbA + (size_t)r * NB * NB * 40 * 64 + lane;
+    const float* __restrict__ Abase0 = ws + l.o_cxbA + (size_t)r * NB * NB * 40 * 64;
+    const unsigned ulane = lane;
     const float* cst = s_c + r * 4 * LEB;
     __syncthreads();
     float dd_sum[S];
@@ -214,10 +217,19 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
             const float mv = valid ? 1.f : 0.f, mo = own ? 1.f : 0.f;
             float* Pu = s_P + ((size_t)(r * NU + sub) * 6) * NSIG;
             for (int e = lane; e < 6 * NSIG; e += 64) Pu[e] = 0.f;
+            // The table base is re-declared opaque (a scalar register pair) in every iteration: otherwise the compiler hoists
+            // the several hundred per-lane 64-bit load addresses of the unrolled chains out of the loop and spills them all.
+            const float* Abase = Abase0;
+            asm volatile("" : "+s"(Abase));
 
             // ---- pass A: per output block H X and (H.H) s, then the per-(window, tap) algebra that does not need e
             float zP[NB][8], zQ[NB][8], al[NB][8], be[NB][8], zz[NB][8], dvv[NB][8];
             float a0 = 0.f, a1 = 0.f, q0 = 0.f, q1 = 0.f, sd0 = 0.f, sd1 = 0.f, vs = 0.f;
+            // the A operands of block pair p + 1 are requested before the MFMA chain of pair p is issued; the empty asm
+            // statements keep the compiler from hoisting more than that one pair of loads (register budget)
+            float cur[24], nxt[24];
+#pragma unroll
+            for (int s = 0; s < 24; ++s) cur[s] = Abase[s * 64 + ulane];
 #pragma unroll
             for (int xb = 0; xb < NB; ++xb) {
                 f32x16 U, TT;
@@ -225,17 +237,22 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                 for (int g = 0; g < 16; ++g) { U[g] = 0.f; TT[g] = 0.f; }
 #pragma unroll
                 for (int jb = 0; jb < NB; ++jb) {
-                    const float* A = Abase + (size_t)(xb * NB + jb) * 40 * 64;
-                    float av[24];
+                    asm volatile("" ::: "memory");
+                    if (xb * NB + jb + 1 < NB * NB) {
+                        const float* A = Abase + (size_t)(xb * NB + jb + 1) * 40 * 64;
 #pragma unroll
-                    for (int s = 0; s < 24; ++s) av[s] = A[s * 64];
+                        for (int s = 0; s < 24; ++s) nxt[s] = A[s * 64 + ulane];
+                    }
+                    asm volatile("" ::: "memory");
 #pragma unroll
                     for (int s = 0; s < 16; ++s) {
                         const int k = 2 * s + h;
-                        U = MFMA32(av[s], s_mu[(k >> 4) * MS + tsl + i + 16 * jb + (k & 15)], U);
+                        U = MFMA32(cur[s], s_mu[(k >> 4) * MS + tsl + i + 16 * jb + (k & 15)], U);
                     }
 #pragma unroll
-                    for (int s = 0; s < 8; ++s) TT = MFMA32(av[16 + s], s_S[tsl + i + 16 * jb + 2 * s + h], TT);
+                    for (int s = 0; s < 8; ++s) TT = MFMA32(cur[16 + s], s_S[tsl + i + 16 * jb + 2 * s + h], TT);
+#pragma unroll
+                    for (int s = 0; s < 24; ++s) cur[s] = nxt[s];
                 }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -276,6 +293,9 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
             e0 *= mv; e1 *= mv;
 
             // ---- pass B: per output block H w, the anti-diagonal sums of the moment gradients, dE/dH
+            float curh[16], nxth[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) curh[s] = Abase[(24 + s) * 64 + ulane];
 #pragma unroll
             for (int xb = 0; xb < NB; ++xb) {
                 f32x16 HW;
@@ -283,12 +303,17 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                 for (int g = 0; g < 16; ++g) HW[g] = 0.f;
 #pragma unroll
                 for (int jb = 0; jb < NB; ++jb) {
-                    const float* A = Abase + ((size_t)(xb * NB + jb) * 40 + 24) * 64;
-                    float av[16];
+                    asm volatile("" ::: "memory");
+                    if (xb * NB + jb + 1 < NB * NB) {
+                        const float* A = Abase + ((size_t)(xb * NB + jb + 1) * 40 + 24) * 64;
 #pragma unroll
-                    for (int s = 0; s < 16; ++s) av[s] = A[s * 64];
+                        for (int s = 0; s < 16; ++s) nxth[s] = A[s * 64 + ulane];
+                    }
+                    asm volatile("" ::: "memory");
 #pragma unroll
-                    for (int s = 0; s < 16; ++s) HW = MFMA32(av[s], s < 8 ? al[jb][s & 7] : be[jb][s & 7], HW);
+                    for (int s = 0; s < 16; ++s) HW = MFMA32(curh[s], s < 8 ? al[jb][s & 7] : be[jb][s & 7], HW);
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) curh[s] = nxth[s];
                 }
                 // anti-diagonal sums (symbol = window + tap), one pair of quantities per round through the wave's
                 // zero-padded buffers; LDS instructions of one wave execute in program order
@@ -351,7 +376,7 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                     }
 #pragma unroll
                     for (int jb = 0; jb < NB; ++jb) {
-#pragma unroll
+        #pragma unroll
                         for (int st = 0; st < 8; ++st) {
                             const int w = tsl + 4 * st + kq + 16 * jb + xa;
                             const float ma = s_mu[w], mb = s_mu[MS + w];
