@@ -155,6 +155,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2-symbols", type=int, default=22, help="symbols per GPU = 2^this")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--channel-memory", type=int, default=25, help="L (65 with --order 64 = BASELINE.json configs[3] per GPU)")
+    ap.add_argument("--lags", type=int, default=25, help="equaliser lags l1 = l2")
+    ap.add_argument("--order", type=int, default=16, help="QAM order")
     ap.add_argument("--workload", choices=["train_step", "sweep"], default="train_step",
                     help="train_step: the headline configuration (default); sweep: 1024 independent real PAM-4 models, L=15")
     args = ap.parse_args()
@@ -182,7 +185,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    L, S, l1, l2, order = 25, 2, 25, 25, 16
+    L, S, l1, l2, order = args.channel_memory, 2, args.lags, args.lags, args.order
     M = int(round(np.sqrt(order)))
     b_per_gpu = 1 << args.log2_symbols
     b_glob = b_per_gpu * world
@@ -277,7 +280,7 @@ def main():
         try:  # HBM bytes per launch of the dominant kernel, measured with rocprofv3 --pmc passes (committed under profiles/)
             with open(os.path.join(ROOT, "profiles", "latest_traffic.json")) as fh:
                 tr = json.load(fh)
-            if dom == "elbo_fused" and world == 1 and args.log2_symbols == 22:
+            if dom == "elbo_fused" and world == 1 and args.log2_symbols == 22 and (L, l1, order) == (25, 25, 16):
                 traffic = next(v for k, v in tr.items() if "k_elbo_cx2" in k)
         except Exception:
             traffic = None
@@ -286,7 +289,7 @@ def main():
             "value": b_glob * args.steps / elapsed, "unit": "symbols/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"complex 16-QAM V2VAE train step, L=25, l1=l2=25, sps=2, one batch of {world}x2^{args.log2_symbols} symbols, "
+            "config": {"workload": f"complex {order}-QAM V2VAE train step, L={L}, l1=l2={l1}, sps=2, one batch of {world}x2^{args.log2_symbols} symbols, "
                                    "Adam-AMSGrad, random-init (dirac) kernels, synthetic Wiener-Hammerstein ISI at 16 dB",
                        "symbols_per_gpu": b_per_gpu, "parallelism": f"halo-sharded dp{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",

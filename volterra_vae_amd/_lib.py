@@ -14,7 +14,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libv2vae_hip.so")
+# V2VAE_LIB_PATH: diagnostic builds of the same library (tools/), never a different backend
+LIB_PATH = os.environ.get("V2VAE_LIB_PATH") or os.path.join(_HERE, "libv2vae_hip.so")
 
 OK, EINVAL, EHALO, ELAUNCH, ESIZE = 0, -1, -2, -3, -4
 _ERR = {EINVAL: "invalid argument / unsupported shape", EHALO: "local sample or symbol range does not cover the halo",
