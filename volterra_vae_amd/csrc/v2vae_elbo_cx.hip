@@ -17,9 +17,8 @@
 // permuted to match); only the dE/dH accumulation, which sums over windows (= lanes), goes through a
 // per-wave transposing LDS buffer.
 //
-// One workgroup = 4 waves; wave w works on phase w % S.  A block tile is CX_TWB windows per phase
-// (TS = CX_TWB - kmax owned symbols plus the kmax halo windows recomputed on the left), so every
-// per-symbol gradient is completed inside the block and gathered without atomics.
+// A block tile is 256 windows per phase (TS = 256 - kmax owned symbols plus the kmax halo windows recomputed on the
+// left), so every per-symbol gradient is completed inside the block and gathered without atomics.
 #include <hip/hip_runtime.h>
 
 #include "v2vae_cx_common.h"
@@ -28,294 +27,8 @@
 namespace v2vae {
 
 
-template <int S>
-__global__ __launch_bounds__(NT) void k_elbo_cx(Lay l, const float* __restrict__ y, float* __restrict__ ws) {
-    extern __shared__ float sm[];
-    constexpr int TWB = CX_TWB, MS = CX_MS, TP = CX_TP;
-    constexpr int NWP = 4 / S;               // waves per phase
-    float* s_mom = sm;                       // [2 streams][4][MS]
-    float* s_S = s_mom + 8 * MS;             // [MS]   v_a + v_b
-    float* s_yw = s_S + MS;                  // [2 outputs][S][TWB]
-    float* s_D = s_yw + 2 * S * TWB;         // [S][6][16][TWB]
-    float* s_T = s_D + S * 6 * 16 * TWB;     // [4 waves][32][TP]
-    __shared__ double dred[NT / 64];
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int i = lane & 31, h = lane >> 5;
-    const int r = wv % S, wsub = wv / S;
-    float* Tb = s_T + wv * 32 * TP;
-    const float* __restrict__ mom = ws + l.o_mom;
-    float* __restrict__ gmom = ws + l.o_gmom;
-    const int64_t own_hi = l.own_lo + l.own_cnt, sym_hi = l.sym_lo + l.sym_cnt;
-    const int TS = TWB - l.kmax;
-
-    // ---- constant MFMA A operands of this wave's phase (row index j = lane & 31)
-    const float* __restrict__ Hr = ws + l.o_cxH + (size_t)(r * 2 + 0) * 256;
-    const float* __restrict__ Hi = ws + l.o_cxH + (size_t)(r * 2 + 1) * 256;
-    const float* __restrict__ h1r = ws + l.o_cxh1 + (r * 2 + 0) * 16;
-    const float* __restrict__ h1i = ws + l.o_cxh1 + (r * 2 + 1) * 16;
-    const int cj = i >> 4, yj = i & 15;
-    float cU[16], cH[16], cT[8], c_hr[8], c_hi[8], c_dr[8], c_di[8];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        {   // [[Hr, Hi], [-Hi, Hr]], natural k order k = 2 s + h
-            const int k = 2 * s + h, ck = k >> 4, xk = k & 15;
-            const float a = Hr[xk * 16 + yj], b = Hi[xk * 16 + yj];
-            cU[s] = ck == 0 ? (cj == 0 ? a : b) : (cj == 0 ? -b : a);
-        }
-        {   // [[Hr, -Hi], [Hi, Hr]], k-slot (s, h) <-> row (s >> 3, kk(s & 7, h)) of [alpha | beta]
-            const int ck = s >> 3, xk = cx_kk(s & 7, h);
-            const float a = Hr[xk * 16 + yj], b = Hi[xk * 16 + yj];
-            cH[s] = ck == 0 ? (cj == 0 ? a : -b) : (cj == 0 ? b : a);
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        const int x = 2 * s + h;
-        const float a = Hr[yj * 16 + x], b = Hi[yj * 16 + x];
-        cT[s] = cj == 0 ? a * a + b * b : 0.f;
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int x = cx_kk(q, h);
-        c_hr[q] = h1r[x]; c_hi[q] = h1i[x];
-        c_dr[q] = Hr[x * 16 + x]; c_di[q] = Hi[x * 16 + x];
-    }
-
-    f32x16 R, Ps;
-#pragma unroll
-    for (int g = 0; g < 16; ++g) { R[g] = 0.f; Ps[g] = 0.f; }
-    float ghr[8], ghi[8], gdr[8], gdi[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { ghr[q] = 0.f; ghi[q] = 0.f; gdr[q] = 0.f; gdi[q] = 0.f; }
-    double Eacc = 0.0;
-
-    for (int tile = blockIdx.x; tile < l.ntile_cx; tile += gridDim.x) {
-        const int64_t s0 = l.own_lo + (int64_t)tile * TS;
-        const int64_t s1 = (s0 + TS < own_hi) ? s0 + TS : own_hi;
-        const int64_t tbase = s0 - l.kmax;
-        __syncthreads();
-        // ---- stage moments (symbol slot ms <-> symbol tbase + ms), s = v_a + v_b, y' per phase
-        for (int idx = tid; idx < 8 * MS; idx += NT) {
-            const int cq = idx / MS, ms = idx - cq * MS;
-            const int64_t m = tbase + ms;
-            s_mom[idx] = (m >= l.sym_lo && m < sym_hi) ? mom[(int64_t)cq * l.sym_cnt + (m - l.sym_lo)] : 0.f;
-        }
-        for (int ms = tid; ms < MS; ms += NT) {
-            const int64_t m = tbase + ms;
-            s_S[ms] = (m >= l.sym_lo && m < sym_hi)
-                          ? mom[(int64_t)1 * l.sym_cnt + (m - l.sym_lo)] + mom[(int64_t)5 * l.sym_cnt + (m - l.sym_lo)] : 0.f;
-        }
-        for (int idx = tid; idx < 2 * S * TWB; idx += NT) {
-            const int o = idx / (S * TWB), rem = idx - o * S * TWB;
-            const int rr = rem / TWB, slot = rem - rr * TWB;
-            const int64_t t = tbase + slot, n = t * S + rr;
-            float v = 0.f;
-            if (t < s1 && n >= 0 && n < l.W) {
-                const int64_t loc = l.pre + n - l.y_lo;
-                if (loc >= 0 && loc < l.y_len) v = y[(int64_t)o * l.y_stride + loc];
-            }
-            s_yw[idx] = v;
-        }
-        __syncthreads();
-
-        for (int sub = wsub; sub < TWB / 32; sub += NWP) {
-            const int tsl = sub * 32;
-            const int64_t t = tbase + tsl + i, n = t * S + r;
-            const bool valid = (t < s1) && n >= 0 && n < l.W;
-            const bool own = valid && t >= s0;
-            const float mv = valid ? 1.f : 0.f, mo = own ? 1.f : 0.f;
-            const unsigned long long bal = __ballot(own);
-
-            // ---- H X and (H.H) s
-            f32x16 U, TT;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) { U[g] = 0.f; TT[g] = 0.f; }
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int k = 2 * s + h;
-                const float b = s_mom[((k >> 4) * 4 + 0) * MS + tsl + i + (k & 15)];
-                U = MFMA32(cU[s], b, U);
-            }
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const float b = s_S[tsl + i + 2 * s + h];
-                TT = MFMA32(cT[s], b, TT);
-            }
-
-            // ---- per-(window, tap) algebra, part 1
-            float zP[8], zQ[8], al[8], be[8], zz[8], dka[8], dkb[8], mua[8], mub[8], dvv[8], tdr[8], tdi[8];
-            float a0 = 0.f, a1 = 0.f, q0 = 0.f, q1 = 0.f, sd0 = 0.f, sd1 = 0.f, vs = 0.f;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int slot = tsl + i + cx_kk(q, h);
-                const float P = U[q], Q = U[q + 8], T = TT[q];
-                const float ma = s_mom[0 * MS + slot], va = s_mom[1 * MS + slot], ka = s_mom[2 * MS + slot], ga = s_mom[3 * MS + slot];
-                const float mb = s_mom[4 * MS + slot], vb = s_mom[5 * MS + slot], kb = s_mom[6 * MS + slot], gb = s_mom[7 * MS + slot];
-                const float hr = c_hr[q], hi = c_hi[q], dr = c_dr[q], di = c_di[q];
-                const float zp = fmaf(2.f, P, hr), zq = fmaf(2.f, Q, hi);
-                a0 += hr * ma - hi * mb;
-                a1 += hi * ma + hr * mb;
-                q0 += ma * P - mb * Q;
-                q1 += ma * Q + mb * P;
-                const float Sv = va + vb, dv = va - vb, gs = ga + gb;
-                sd0 = fmaf(dv, dr, sd0);
-                sd1 = fmaf(dv, di, sd1);
-                const float z2 = zp * zp + zq * zq;
-                const float ca = dr * zp + di * zq, cb = dr * zq - di * zp;
-                vs += Sv * z2 + 2.f * Sv * T + 2.f * (ka * ca + kb * cb) + gs * (dr * dr + di * di);
-                al[q] = 2.f * Sv * zp + 2.f * (ka * dr - kb * di);
-                be[q] = 2.f * Sv * zq + 2.f * (ka * di + kb * dr);
-                zP[q] = zp; zQ[q] = zq;
-                zz[q] = z2 + 4.f * T;
-                dka[q] = 2.f * ca; dkb[q] = 2.f * cb;
-                mua[q] = ma; mub[q] = mb; dvv[q] = dv;
-                tdr[q] = 2.f * (ka * zp + kb * zq) + 2.f * gs * dr;
-                tdi[q] = 2.f * (ka * zq - kb * zp) + 2.f * gs * di;
-            }
-            a0 += __shfl_xor(a0, 32); a1 += __shfl_xor(a1, 32);
-            q0 += __shfl_xor(q0, 32); q1 += __shfl_xor(q1, 32);
-            sd0 += __shfl_xor(sd0, 32); sd1 += __shfl_xor(sd1, 32);
-            vs += __shfl_xor(vs, 32);
-            const float y0 = s_yw[(0 * S + r) * TWB + tsl + i], y1 = s_yw[(1 * S + r) * TWB + tsl + i];
-            float e0 = a0 + q0 + sd0 - y0, e1 = a1 + q1 + sd1 - y1;
-            if (own && h == 0) Eacc += (double)(e0 * e0 + e1 * e1 + vs);
-            e0 *= mv; e1 *= mv;
-
-            // ---- sum over outputs of H w; B operand straight from registers
-            f32x16 HW;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) HW[g] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) HW = MFMA32(cH[s], s < 8 ? al[s & 7] : be[s & 7], HW);
-
-            // ---- part 2: gradients of the moments (to LDS for the gather), rho / sigma, vector gradients
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int x = cx_kk(q, h);
-                const float zp = zP[q], zq = zQ[q], dr = c_dr[q], di = c_di[q];
-                const float ed = 2.f * (e0 * dr + e1 * di);
-                float* D = s_D + ((size_t)(r * 6) * 16 + x) * TWB + tsl + i;
-                D[0 * 16 * TWB] = mv * (2.f * (e0 * zp + e1 * zq) + 2.f * HW[q]);
-                D[1 * 16 * TWB] = mv * (2.f * (e1 * zp - e0 * zq) + 2.f * HW[q + 8]);
-                D[2 * 16 * TWB] = mv * (zz[q] + ed);
-                D[3 * 16 * TWB] = mv * (zz[q] - ed);
-                D[4 * 16 * TWB] = mv * dka[q];
-                D[5 * 16 * TWB] = mv * dkb[q];
-                const float gr = 2.f * (e0 * mua[q] + e1 * mub[q]), gi = 2.f * (e1 * mua[q] - e0 * mub[q]);
-                ghr[q] += mo * (gr + al[q]);
-                ghi[q] += mo * (gi + be[q]);
-                gdr[q] += mo * (2.f * e0 * dvv[q] + tdr[q]);
-                gdi[q] += mo * (2.f * e1 * dvv[q] + tdi[q]);
-                Tb[i * TP + x] = mo * (gr + 2.f * al[q]);
-                Tb[i * TP + 16 + x] = mo * (gi + 2.f * be[q]);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-            // ---- dE/dH and s s^T accumulation over this subtile's windows
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int w = 2 * s + h;
-                const float a = Tb[w * TP + i];
-                const float b = s_mom[(cj * 4 + 0) * MS + tsl + w + yj];
-                R = MFMA32(a, b, R);
-            }
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int w = 2 * s + h;
-                const float sv = s_S[tsl + w + i];
-                const float a = ((bal >> w) & 1ull) ? sv : 0.f;
-                Ps = MFMA32(a, sv, Ps);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-        __syncthreads();
-        // ---- gather: symbol m = t + kk collects window t = m - kk of every phase
-        for (int idx = tid; idx < 2 * TS; idx += NT) {
-            const int c = idx / TS, ml = idx - c * TS;
-            const int64_t m = s0 + ml;
-            if (m < s1) {
-                float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
-                for (int rr = 0; rr < S; ++rr) {
-                    const float* Hrr = ws + l.o_cxH + (size_t)(rr * 2 + 0) * 256;
-                    const float* Hir = ws + l.o_cxH + (size_t)(rr * 2 + 1) * 256;
-                    for (int kk = 0; kk < l.LE; ++kk) {
-                        const int tsl = ml + l.kmax - kk;
-                        const float* D = s_D + ((size_t)(rr * 6 + c) * 16 + kk) * TWB + tsl;
-                        g0 += D[0];
-                        g1 += D[2 * 16 * TWB];
-                        g2 += D[4 * 16 * TWB];
-                        const int64_t t = m - kk, n = t * S + rr;
-                        if (n >= 0 && n < l.W) {
-                            const float dr = Hrr[kk * 16 + kk], di = Hir[kk * 16 + kk];
-                            g3 += dr * dr + di * di;
-                        }
-                    }
-                }
-                float* gp = gmom + (int64_t)c * 4 * l.sym_cnt + (m - l.sym_lo);
-                gp[0] = g0; gp[l.sym_cnt] = g1; gp[2 * l.sym_cnt] = g2; gp[3 * l.sym_cnt] = g3;
-            }
-        }
-    }
-
-    // ---- one record per (block, phase): R [32][32], Ps [32][32], vectors [4][16]; the waves of a phase are
-    //      reduced through LDS in a fixed order
-    __syncthreads();
-    float* img = s_D + (size_t)r * CX_REC;
-    float vsum[8][4];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        float v0 = ghr[q], v1 = ghi[q], v2 = gdr[q], v3 = gdi[q];
-#pragma unroll
-        for (int off = 1; off < 32; off <<= 1) {
-            v0 += __shfl_xor(v0, off); v1 += __shfl_xor(v1, off);
-            v2 += __shfl_xor(v2, off); v3 += __shfl_xor(v3, off);
-        }
-        vsum[q][0] = v0; vsum[q][1] = v1; vsum[q][2] = v2; vsum[q][3] = v3;
-    }
-    for (int w = 0; w < NWP; ++w) {
-        if (wsub == w) {
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int e = ((g & 3) + 8 * (g >> 2) + 4 * h) * 32 + i;
-                if (w == 0) { img[e] = R[g]; img[1024 + e] = Ps[g]; }
-                else { img[e] += R[g]; img[1024 + e] += Ps[g]; }
-            }
-            if (i == 0) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int x = cx_kk(q, h);
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        if (w == 0) img[2048 + v * 16 + x] = vsum[q][v];
-                        else img[2048 + v * 16 + x] += vsum[q][v];
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-    float* rec = ws + l.o_part_cx + (size_t)blockIdx.x * S * CX_REC;
-    for (int e = tid; e < S * CX_REC; e += NT) rec[e] = s_D[e];
-    // E partial of the block
-    double v = Eacc;
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    __syncthreads();
-    if (lane == 0) dred[wv] = v;
-    __syncthreads();
-    if (tid == 0) {
-        double s = 0.0;
-        for (int w = 0; w < NT / 64; ++w) s += dred[w];
-        reinterpret_cast<double*>(ws + l.o_Epart)[blockIdx.x] = s;
-    }
-}
-
-
 // ------------------------------------------------------------------------------------------------------------
-// Second generation: 8 waves per workgroup (two per SIMD, so one wave's per-tap algebra overlaps the other's MFMA
+// 8 waves per workgroup (two per SIMD, so one wave's per-tap algebra overlaps the other's MFMA
 // chain), constant A operands in LDS, block tiles of 256 windows per phase, and an LDS-lean gather: each wave sums
 // its own 32 x Le tile of per-(window, tap) gradients along the anti-diagonals (symbol = window + tap) into a
 // 47-entry partial per (phase, subtile); the block then adds the <= 2 x S partials that cover a symbol in a fixed order.
@@ -843,11 +556,10 @@ __global__ __launch_bounds__(NT) void k_chain_channel_cx(Lay l, const float* __r
             if (ri == rj) {
                 const float* tot = ws + l.o_tot_cx + (size_t)ri * CX_REC;
                 const float* Rm = tot;
-                const float* Pm = tot + 1024;
                 const float* Hp = ws + l.o_cxH + (size_t)(ri * 2 + p) * 256;
                 auto G = [&](int a, int b) {
                     float g = (p == 0) ? Rm[a * 32 + b] + Rm[(16 + a) * 32 + 16 + b] : Rm[(16 + a) * 32 + b] - Rm[a * 32 + 16 + b];
-                    g += 4.f * Hp[a * 16 + b] * (l.cx_gen == 2 ? psum_value(l, ws, ri, a, b) : Pm[a * 32 + b]);
+                    g += 4.f * Hp[a * 16 + b] * psum_value(l, ws, ri, a, b);
                     if (a == b) g += tot[2048 + (2 + p) * 16 + a];
                     return g;
                 };
@@ -860,28 +572,16 @@ __global__ __launch_bounds__(NT) void k_chain_channel_cx(Lay l, const float* __r
 
 int launch_elbo_cx(const Lay& l, const float* y, float* ws, hipStream_t st) {
     const int lds = l.lds_cx;
-    hipError_t e = hipSuccess;
-    if (l.cx_gen == 2) {
-#define V2VAE_LAUNCH_CX2(SS, NWV)                                                                                          \
+#define V2VAE_LAUNCH_CX2(SS)                                                                                               \
     do {                                                                                                                   \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_elbo_cx2<SS, NWV>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-        if (e != hipSuccess) return V2VAE_ELAUNCH;                                                                         \
-        hipLaunchKernelGGL((k_elbo_cx2<SS, NWV>), dim3(l.nblk_cx), dim3(NWV * 64), lds, st, l, y, ws);                      \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_elbo_cx2<SS, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                lds) != hipSuccess)                                                                        \
+            return V2VAE_ELAUNCH;                                                                                          \
+        hipLaunchKernelGGL((k_elbo_cx2<SS, 8>), dim3(l.nblk_cx), dim3(8 * 64), lds, st, l, y, ws);                          \
     } while (0)
-        if (l.cx_waves == 8) { if (l.S == 1) V2VAE_LAUNCH_CX2(1, 8); else V2VAE_LAUNCH_CX2(2, 8); }
-        else { if (l.S == 1) V2VAE_LAUNCH_CX2(1, 4); else V2VAE_LAUNCH_CX2(2, 4); }
+    if (l.S == 1) V2VAE_LAUNCH_CX2(1);
+    else V2VAE_LAUNCH_CX2(2);
 #undef V2VAE_LAUNCH_CX2
-        return V2VAE_OK;
-    }
-    if (l.S == 1) {
-        if (lds > 64 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_elbo_cx<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return V2VAE_ELAUNCH;
-        hipLaunchKernelGGL(k_elbo_cx<1>, dim3(l.nblk_cx), dim3(NT), lds, st, l, y, ws);
-    } else {
-        if (lds > 64 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_elbo_cx<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return V2VAE_ELAUNCH;
-        hipLaunchKernelGGL(k_elbo_cx<2>, dim3(l.nblk_cx), dim3(NT), lds, st, l, y, ws);
-    }
     return V2VAE_OK;
 }
 

@@ -124,17 +124,11 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     }
     // ---- matrix-core ELBO path: complex model, <= 16 active taps per stream and phase, S in {1, 2}
     l.use_cx = (l.mode == 1 && l.LE <= 16 && l.S <= 2 && getenv("V2VAE_FORCE_GENERIC") == nullptr) ? 1 : 0;
-    l.cx_gen = getenv("V2VAE_CX_GEN1") ? 1 : 2;
-    l.cx_waves = getenv("V2VAE_CX_WAVES4") ? 4 : 8;
     {
-        const int twb = l.cx_gen == 2 ? 256 : CX_TWB;
-        const int ts = twb - l.kmax;
+        const int ts = 256 - l.kmax;
         l.ntile_cx = (int)((l.own_cnt + ts - 1) / ts);
         l.nblk_cx = l.ntile_cx < CX_BLOCKS ? l.ntile_cx : CX_BLOCKS;
-        if (l.cx_gen == 2)
-            l.lds_cx = ((11 * (256 + 48) + 2 * l.S * 256) + l.S * 40 * 64 + l.S * 64 + 8 * 32 * CX_TP + 8 * 2 * (16 + 16 * 48) + l.S * 8 * 6 * 64) * 4;
-        else
-            l.lds_cx = (8 * CX_MS + CX_MS + 2 * l.S * CX_TWB + l.S * 6 * 16 * CX_TWB + 4 * 32 * CX_TP) * 4;
+        l.lds_cx = ((11 * (256 + 48) + 2 * l.S * 256) + l.S * 40 * 64 + l.S * 64 + 8 * 32 * CX_TP + 8 * 2 * (16 + 16 * 48) + l.S * 8 * 6 * 64) * 4;
         // blocked variant for longer channels
         l.use_cxb = (l.mode == 1 && l.LE > 16 && l.LE <= 48 && l.S <= 2 && getenv("V2VAE_FORCE_GENERIC") == nullptr) ? 1 : 0;
         l.cxb_nb = (l.LE + 15) / 16;
@@ -1506,7 +1500,7 @@ int v2vae_demap_moments(const v2vae_problem* p, const float* xhat, const float* 
     else if (l.C <= 8) V2VAE_LAUNCH_DEMAP(8);
     else V2VAE_LAUNCH_DEMAP(16);
 #undef V2VAE_LAUNCH_DEMAP
-    if ((l.use_cx && l.cx_gen == 2) || l.use_cxb) launch_psum_cx(l, (float*)ws, (hipStream_t)stream);
+    if (l.use_cx || l.use_cxb) launch_psum_cx(l, (float*)ws, (hipStream_t)stream);
     return launch_status();
 }
 

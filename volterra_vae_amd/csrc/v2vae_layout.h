@@ -23,8 +23,6 @@ constexpr int LDS_BUDGET = 163000;  // one workgroup may use (almost) all 160 Ki
 constexpr int SCRATCH_F = 4096; // floats of LDS scratch for cross-chunk reductions
 constexpr int MAX_BLOCKS = 512; // persistent workgroups per kernel (2 per CU)
 // matrix-core ELBO kernel for the complex model (v2vae_elbo_cx.hip)
-constexpr int CX_TWB = 128;          // windows per phase per block tile
-constexpr int CX_MS = CX_TWB + 48;   // staged symbol slots per block tile
 constexpr int CX_TP = 33;            // row pitch of the per-wave transposing buffer
 constexpr int CX_REC = 2112;         // floats per wave record: R 32x32, Ps 32x32, 4 vectors of 16
 constexpr int SUM_CHUNKS = 32;       // first-stage groups of the two-stage partial-record sums
@@ -50,7 +48,7 @@ struct Lay {
     int lds_eq;              // bytes (forward and backward use the same carve)
     int nblk_sym;
     // matrix-core ELBO path
-    int use_cx, cx_gen, cx_waves, ntile_cx, nblk_cx, lds_cx, nblk_E, nblk_psum;
+    int use_cx, ntile_cx, nblk_cx, lds_cx, nblk_E, nblk_psum;
     int64_t o_psum_part, o_psum_tot;
     int64_t o_cxH, o_cxh1, o_part_cx, o_tot_cx;
     // blocked matrix-core ELBO path (complex, 16 < active taps per phase <= 48): taps in blocks of 16
