@@ -20,6 +20,11 @@
  *   h1 [L], h2 [L][L], k1 [l1], k2 [l2][l2]
  * mode 1 (complex, holomorphic second-order kernels; Re plane then Im plane):
  *   h1 [2][L], h2 [2][L][L], k1 [2][l1], k2 [2][l2][l2]
+ * mode 2 (real, memory-polynomial channel, lib/real_equalization.py:1238-1246, ELBO :1304-1354):
+ *   h1 [L], h2 [L] (per-tap weight of x^2), k1, k2 as mode 0
+ * mode 3 (real, Hammerstein channel, lib/real_equalization.py:1053-1058, ELBO :1117-1167):
+ *   h1 [L] = channel_h, h2 [2] = (alpha_1, alpha_2), k1, k2 as mode 0
+ * Modes 2 and 3 are the second-order model with a diagonal kernel and run on the mode-0 kernels.
  * l2 = 0 selects a linear FIR equaliser (lib/real_equalization.py:971-982) and k2 may be NULL.
  */
 #ifndef V2VAE_HIP_H
@@ -40,7 +45,8 @@ extern "C" {
 
 typedef struct v2vae_problem {
     int32_t ns;      /* 1 or 2 */
-    int32_t mode;    /* 0 real (bug-compatible with lib/real_equalization.py:869), 1 complex */
+    int32_t mode;    /* 0 real (bug-compatible with lib/real_equalization.py:869), 1 complex,
+                        2 real with memory-polynomial channel, 3 real with Hammerstein channel */
     int32_t sps;     /* samples per symbol S */
     int32_t l1;      /* first-order equaliser taps */
     int32_t pad1;    /* left zero padding of the first-order part (l1/2 for the Volterra equaliser,
@@ -112,7 +118,8 @@ int v2vae_eq_bwd(const v2vae_problem* p, const float* y, const float* gxhat, voi
 
 /* Reduce all partial sums and chain them to raw-parameter gradients.  Any output may be NULL.
  * which: bit 0 = channel (g_h1, g_h2: scaled by scal[LAMBDA] and grad_scale), bit 1 = noise scaling
- * (g_scaling [ns][C]), bit 2 = equaliser (g_k1, g_k2). */
+ * (g_scaling [ns][C]), bit 2 = equaliser (g_k1, g_k2), bit 3 = ADD the noise-scaling gradient to g_scaling instead of
+ * overwriting it (lib/real_equalization.py:1169-1178 and :1356-1364 never reset that gradient). */
 int v2vae_finish_grads(const v2vae_problem* p, void* ws, const double* scal, const float* grad_scale,
                        int which, float* g_h1, float* g_h2, float* g_k1, float* g_k2,
                        float* g_scaling, void* stream);
@@ -153,7 +160,8 @@ typedef struct v2vae_train_args {
     int32_t adaptive_noise;  /* lib/real_equalization.py:921-923 */
     int32_t freeze_h2;       /* 1: the second-order channel kernel is not updated; with h2 = 0 and unit scaling this is the
                                 linear-channel VAE of lib/real_equalization.py:564-690 (same ELBO, :629-664) */
-    int32_t reserved;
+    int32_t accumulate_scaling_grad;  /* 1: the scaling section of `grads` is a running sum over steps (the memory-polynomial
+                                and Hammerstein VAEs never reset that gradient: lib/real_equalization.py:1169-1178, :1356-1364) */
 } v2vae_train_args;
 
 /* One whole single-GPU training step of GenericTorchBlindEqualizer.fit's loop body
@@ -187,6 +195,7 @@ typedef struct v2vae_fit_args {
     int32_t learn_scaling;
     int32_t adaptive_noise;
     int32_t freeze_h2;        /* as in v2vae_train_args */
+    int32_t accumulate_scaling_grad;  /* as in v2vae_train_args; the scaling section of `grads` is read on entry */
 } v2vae_fit_args;
 
 /* Host-side helper (no GPU work): per-step Adam constants of v2vae_adam_amsgrad for steps

@@ -1,0 +1,136 @@
+"""GPU tests of the memory-polynomial and Hammerstein channel VAE drop-ins (reference SecondVolterraMPVAE / SecondVolterraHVAE,
+lib/real_equalization.py:1040-1410) against golden vectors produced by the reference
+(tests/golden/make_golden_polynomial_channel.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-5  # fp32 relative tolerance of the hot path; the reference's own fp32-vs-fp64 distance is added where it dominates
+
+
+def rel(a, b):
+    a = np.asarray(a.detach().cpu() if torch.is_tensor(a) else a, dtype=np.float64).reshape(-1)
+    b = np.asarray(b, dtype=np.float64).reshape(-1)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def make(g):
+    from volterra_vae_amd.real_equalization import SecondVolterraHVAE, SecondVolterraMPVAE
+    sched = str(g["lr_schedule"]) if "lr_schedule" in g.files else "step"
+    kw = dict(channel_memory=int(g["L"]), learning_rate=float(g["lr"]) if "lr" in g.files else 5e-3,
+              constellation=g["constellation"], samples_per_symbol=int(g["S"]), batch_size=int(g["B"]),
+              noise_variance=float(g["noise_variance_in"]), torch_device=torch.device("cuda"),
+              lr_schedule=None if sched == "none" else sched, equaliser_n_lags1=int(g["l1"]), equaliser_n_lags2=int(g["l2"]))
+    if str(g["kind"]) == "mpvae":
+        learn = bool(int(g["learn_noise_scaling"])) if "learn_noise_scaling" in g.files else True
+        return SecondVolterraMPVAE(noise_scaling=learn, **kw)
+    return SecondVolterraHVAE(**kw)
+
+
+def load_channel(m, g):
+    with torch.no_grad():
+        if str(g["kind"]) == "mpvae":
+            m.channel_h1.copy_(torch.from_numpy(g["h1"]))
+            m.channel_h2.copy_(torch.from_numpy(g["h2"]))
+        else:
+            m.channel_h.copy_(torch.from_numpy(g["h"]))
+            m.alpha_1.fill_(float(g["alpha1"]))
+            m.alpha_2.fill_(float(g["alpha2"]))
+
+
+@pytest.mark.parametrize("case", ["mpvae", "mpvae_L8S1", "mpvae_L10S3", "hvae", "hvae_L8S1"])
+def test_single_step_loss_and_gradients(case):
+    g32 = np.load(os.path.join(GOLDEN, f"poly_real_step_{case}_f32.npz"))
+    g64 = np.load(os.path.join(GOLDEN, f"poly_real_step_{case}_f64.npz"))
+    m = make(g32)
+    kind = str(g32["kind"])
+    assert repr(m) == ("SecondVolterraMPVAE" if kind == "mpvae" else "SecondVolterraHVAE")
+    names = [p["name"] for p in m.get_parameters()]
+    assert names == (["channel_h1", "channel_h2", "equaliser", "noise_scale"] if kind == "mpvae"
+                     else ["channel_h", "alpha1", "alpha2", "equaliser", "noise_scale"])
+    load_channel(m, g32)
+    with torch.no_grad():
+        m.equaliser.kernel1.copy_(torch.from_numpy(g32["k1"]))
+        m.equaliser.kernel2.copy_(torch.from_numpy(g32["k2"]))
+        m.noise_scaling.copy_(torch.from_numpy(g32["noise_scaling"]))
+    y = torch.from_numpy(g32["rx"]).float().cuda()
+    xhat = m.forward(y)
+    assert rel(xhat, g64["xhat"]) < TOL
+    q = m._soft_demapping(xhat)
+    assert rel(q, g64["q"]) < 1e-4
+    loss = m._calculate_loss(xhat, y)
+    assert abs(float(loss.detach()) - float(g64["loss"])) < TOL * abs(float(g64["loss"]))
+    assert abs(float(m.noise_variance) - float(g64["noise_variance_out"])) < TOL * float(g64["noise_variance_out"])
+    loss.backward()
+
+    def chk(ours, key):
+        own = rel(g32[key], g64[key])
+        assert rel(ours, g64[key]) < TOL + own, (key, rel(ours, g64[key]), own)
+    if kind == "mpvae":
+        chk(m.channel_h1.grad, "g_h1")
+        chk(m.channel_h2.grad, "g_h2")
+    else:
+        chk(m.channel_h.grad, "g_h")
+        chk(m.alpha_1.grad, "g_alpha1")
+        chk(m.alpha_2.grad, "g_alpha2")
+    chk(m.equaliser.kernel1.grad, "g_k1")
+    chk(m.equaliser.kernel2.grad, "g_k2")
+    chk(m.noise_scaling.grad, "g_noise_scaling")
+
+
+@pytest.mark.parametrize("case", ["mpvae", "mpvae_fixed_scaling", "hvae"])
+@pytest.mark.parametrize("persistent", [False, True])
+def test_fit_trajectory_matches_reference(case, persistent):
+    """20 dependent steps incl. the reference's never-reset noise-scaling gradient; persistent=True runs the whole loop in
+    one launch of the stage-by-stage kernel."""
+    g32 = np.load(os.path.join(GOLDEN, f"poly_real_fit_{case}_f32.npz"))
+    g64 = np.load(os.path.join(GOLDEN, f"poly_real_fit_{case}_f64.npz"))
+    m = make(g32)
+    m.persistent_fit = persistent
+    m.initialize_optimizer()
+    y_eq, loss_curve = m.fit(g32["rx"])
+
+    def chk(ours, key, tol):
+        own = rel(g32[key], g64[key])
+        assert rel(ours, g64[key]) < tol + own, (key, rel(ours, g64[key]), own)
+    chk(loss_curve, "loss_curve", TOL)
+    chk(y_eq, "y_eq", TOL)
+    if str(g32["kind"]) == "mpvae":
+        chk(m.channel_h1, "h1", TOL)
+        chk(m.channel_h2, "h2", 1e-4)
+    else:
+        chk(m.channel_h, "h", TOL)
+        chk(m.alpha_1, "alpha1", TOL)
+        chk(m.alpha_2, "alpha2", 1e-4)
+    chk(m.equaliser.kernel1, "k1", TOL)
+    chk(m.equaliser.kernel2, "k2", 1e-4)
+    chk(m.noise_scaling, "noise_scaling", TOL)
+    assert abs(float(m.noise_variance) - float(g64["noise_variance_out"])) < TOL * float(g64["noise_variance_out"])
+    q = m.estimate_symbol_probs(g32["rx_val"])
+    assert rel(q, g32["q_val"]) < 1e-4
+    assert (q.argmax(axis=0) == g32["q_val"].argmax(axis=0)).mean() > 0.999
+
+
+def test_hand_stepped_loop_equals_fit():
+    """forward / _calculate_loss / _update_model by hand (the loop body of lib/real_equalization.py:488-496) walks the same
+    trajectory as fit(), including the accumulating noise-scaling gradient."""
+    g32 = np.load(os.path.join(GOLDEN, "poly_real_fit_hvae_f32.npz"))
+    a, b = make(g32), make(g32)
+    a.persistent_fit = False
+    a.lr_schedule = b.lr_schedule = None
+    a.initialize_optimizer()
+    b.initialize_optimizer()
+    S, B = int(g32["S"]), int(g32["B"])
+    n = 6
+    a.fit(g32["rx"][:n * B * S])
+    y = torch.from_numpy(g32["rx"]).float().cuda()
+    for i in range(n):
+        ys = y[i * B * S:(i + 1) * B * S]
+        b._update_model(b._calculate_loss(b.forward(ys), ys))
+    for name in ("channel_h", "alpha_1", "alpha_2", "noise_scaling"):
+        assert rel(getattr(b, name), getattr(a, name).detach().cpu().numpy()) < 2e-5, name
+    assert rel(b.noise_scaling.grad, a.noise_scaling.grad.cpu().numpy()) < 2e-5

@@ -41,7 +41,7 @@ class TrainArgs(C.Structure):
                 ("gxhat", C.c_void_p), ("loss_out", C.c_void_p),
                 ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("step", C.c_int64), ("learn_scaling", C.c_int32), ("adaptive_noise", C.c_int32),
-                ("freeze_h2", C.c_int32), ("reserved", C.c_int32)]
+                ("freeze_h2", C.c_int32), ("accumulate_scaling_grad", C.c_int32)]
 
 
 class FitArgs(C.Structure):
@@ -52,7 +52,7 @@ class FitArgs(C.Structure):
                 ("y_eq", C.c_void_p), ("loss_curve", C.c_void_p), ("step_size", C.c_void_p), ("bc2_sqrt", C.c_void_p),
                 ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("n_models", C.c_int32), ("n_batches", C.c_int32), ("learn_scaling", C.c_int32),
-                ("adaptive_noise", C.c_int32), ("freeze_h2", C.c_int32)]
+                ("adaptive_noise", C.c_int32), ("freeze_h2", C.c_int32), ("accumulate_scaling_grad", C.c_int32)]
 
 
 EXPORTS = {

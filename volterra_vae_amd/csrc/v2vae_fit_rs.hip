@@ -48,7 +48,7 @@ static inline int rs_rup(int x, int m) { return (x + m - 1) / m * m; }
 // Fills `o` and returns 1 if the shape fits this kernel.
 int rs_plan(const Lay& l, int64_t pack, RsOff* o) {
     if (getenv("V2VAE_FORCE_GENERIC")) return 0;
-    if (l.mode != 0 || l.ns != 1 || l.LE > 8 || l.S > 4 || l.l2 > 31 || l.l1 > 64 || l.pad1 > RS_HL || l.C > MAX_C) return 0;
+    if (l.mode != 0 || l.chan != 0 || l.ns != 1 || l.LE > 8 || l.S > 4 || l.l2 > 31 || l.l1 > 64 || l.pad1 > RS_HL || l.C > MAX_C) return 0;
     if (pack > RS_APT * RS_NT || l.b_glob > 4096 || l.n_glob > 8192) return 0;
     const int B = (int)l.b_glob, N = (int)l.n_glob;
     RsOff r{};
@@ -816,7 +816,7 @@ int fit_rs_applicable(const Lay& l, int64_t pack) {
 int launch_fit_rs(const Lay& l, const v2vae_fit_args* a, const int64_t n[5], hipStream_t st) {
     RsOff o;
     const int64_t pack = n[0] + n[1] + n[2] + n[3] + n[4];
-    if (!rs_plan(l, pack, &o)) return 0;
+    if (!rs_plan(l, pack, &o) || a->accumulate_scaling_grad) return 0;  // gradients are overwritten per step in this kernel
     const int lds = o.total * 4;
 #define V2VAE_LAUNCH_RS(CB)                                                                                             \
     do {                                                                                                                \

@@ -22,7 +22,10 @@ static inline int64_t rup(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 int make_layout(const v2vae_problem* p, Lay* out) {
     if (!p || !out) return V2VAE_EINVAL;
     Lay l{};
-    l.ns = p->ns; l.mode = p->mode; l.S = p->sps; l.l1 = p->l1; l.pad1 = p->pad1; l.l2 = p->l2;
+    l.ns = p->ns; l.S = p->sps;
+    if (p->mode < 0 || p->mode > 3) return V2VAE_EINVAL;
+    l.chan = p->mode >= 2 ? p->mode - 1 : 0;  // modes 2, 3: real path with a polynomial channel model
+    l.mode = p->mode >= 2 ? 0 : p->mode; l.l1 = p->l1; l.pad1 = p->pad1; l.l2 = p->l2;
     l.L = p->L; l.C = p->C;
     l.n_glob = p->n_glob; l.y_lo = p->y_lo; l.y_len = p->y_len; l.sym_lo = p->sym_lo;
     l.sym_cnt = p->sym_cnt; l.own_lo = p->own_lo; l.own_cnt = p->own_cnt;
@@ -166,6 +169,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     l.o_HHc = take((int64_t)l.S * l.ns * l.LTp * l.LTp);
     l.o_dc = take((int64_t)l.S * l.ns * l.LTp);
     l.o_dqc = take((int64_t)l.S * l.ns * l.LTp);
+    l.o_chanraw = take(l.chan ? 2 * (int64_t)l.L : 0);
     l.o_mom = take((int64_t)l.ns * 4 * l.sym_cnt);
     l.o_gmom = take((int64_t)l.ns * 4 * l.sym_cnt);
     l.o_part_elbo = take((int64_t)l.nblk_elbo * l.rec_elbo);
@@ -238,6 +242,15 @@ __device__ __forceinline__ float stacked_lin(int mode, const float* __restrict__
     return ca == 0 ? h1[L + ia] : h1[ia];
 }
 
+// Polynomial channel models (real path): coefficient of x and of x^2 at tap a.  h2 is [L] (memory polynomial,
+// lib/real_equalization.py:1333-1334) or [alpha1, alpha2] (Hammerstein, :1146-1147).
+__device__ __forceinline__ float chan_lin(int chan, const float* __restrict__ h1, const float* __restrict__ h2, int a) {
+    return chan == 2 ? h2[0] * h1[a] : h1[a];
+}
+__device__ __forceinline__ float chan_sq(int chan, const float* __restrict__ h1, const float* __restrict__ h2, int a) {
+    return chan == 2 ? h2[1] * h1[a] : h2[a];
+}
+
 // compact tap k of phase r -> stacked original tap index c*L + i, or -1
 __device__ __forceinline__ int tap_index(const Lay& l, int r, int k) {
     const int c = k / l.LEp, kk = k - c * l.LEp;
@@ -290,7 +303,10 @@ __device__ __forceinline__ void d_prep_tables(const GridCtx gc, Lay l, const flo
         const int o = rem / l.LTp, k = rem - o * l.LTp;
         const int a = tap_index(l, r, k);
         float hv = 0.f, dv = 0.f, dqv = 0.f;
-        if (a >= 0) {
+        if (a >= 0 && l.chan) {
+            hv = chan_lin(l.chan, h1, h2, a);
+            dv = dqv = chan_sq(l.chan, h1, h2, a);  // exact expectation of the square term (:1334, :1147)
+        } else if (a >= 0) {
             hv = stacked_lin(l.mode, h1, l.L, o, a);
             dv = stacked_quad(l.mode, h2, l.L, o, a, a);
             dqv = (l.mode == 0) ? h2[a * l.L + a] : dv;  // lib/real_equalization.py:869 uses diag(h2)
@@ -319,9 +335,14 @@ __device__ __forceinline__ void d_prep_tables(const GridCtx gc, Lay l, const flo
         const int r = ro / l.ns, o = ro - r * l.ns;
         const int k = rem / l.LTp, j = rem - k * l.LTp;
         const int a = tap_index(l, r, k), b = tap_index(l, r, j);
-        const float hv = (a >= 0 && b >= 0) ? stacked_quad(l.mode, h2, l.L, o, a, b) : 0.f;
+        float hv = 0.f;
+        if (a >= 0 && b >= 0) hv = l.chan ? (a == b ? chan_sq(l.chan, h1, h2, a) : 0.f) : stacked_quad(l.mode, h2, l.L, o, a, b);
         ws[l.o_Hc + idx] = hv;
         ws[l.o_HHc + idx] = hv * hv;
+    }
+    if (l.chan && h1) {
+        const int n2 = l.chan == 2 ? 2 : l.L;
+        for (int idx = tid; idx < l.L + n2; idx += nth) ws[l.o_chanraw + idx] = idx < l.L ? h1[idx] : h2[idx - l.L];
     }
 }
 
@@ -1164,7 +1185,7 @@ __device__ __forceinline__ float GS_value(const Lay& l, const float* __restrict_
     float v = G[((size_t)o * l.LTp + ka) * l.LTp + kb] + 4.f * Hv * P[(size_t)ka * l.LTp + kb];
     if (a == b) {
         v += V[(o * 3 + 1) * l.LTp + ka];
-        if (l.mode != 0) v += V[(o * 3 + 2) * l.LTp + ka];
+        if (l.mode != 0 || l.chan != 0) v += V[(o * 3 + 2) * l.LTp + ka];
     }
     return v;
 }
@@ -1181,6 +1202,26 @@ __device__ __forceinline__ void d_chain_channel(const GridCtx gc, Lay l, const f
                                                       float* __restrict__ g_h2) {
     const float lam = (float)scal[V2VAE_SCAL_LAMBDA] * (grad_scale ? grad_scale[0] : 1.f);
     const int L = l.L;
+    if (l.chan) {
+        // polynomial channel models: dE/da[i] is the first-order record, dE/db[i] the diagonal of the kernel gradient
+        const float* raw = ws + l.o_chanraw;
+        const int n2c = l.chan == 2 ? 2 : L;
+        for (int idx = gc.bid * NT + threadIdx.x; idx < L + n2c; idx += gc.nb * NT) {
+            if (l.chan == 1) {
+                if (idx < L) { if (g_h1) g_h1[idx] = lam * g1_value(l, ws, 0, idx, 0); }
+                else if (g_h2) g_h2[idx - L] = lam * GS_value(l, ws, 0, idx - L, idx - L);
+            } else if (idx < L) {
+                // h enters as a = alpha1 h and b = alpha2 h (lib/real_equalization.py:1146-1147)
+                if (g_h1) g_h1[idx] = lam * (raw[L] * g1_value(l, ws, 0, idx, 0) + raw[L + 1] * GS_value(l, ws, 0, idx, idx));
+            } else if (g_h2) {
+                float acc = 0.f;
+                for (int i = 0; i < L; ++i)
+                    acc = fmaf(raw[i], idx == L ? g1_value(l, ws, 0, i, 0) : GS_value(l, ws, 0, i, i), acc);
+                g_h2[idx - L] = lam * acc;
+            }
+        }
+        return;
+    }
     const int n1 = l.ns * L, n2 = l.ns * L * L;
     for (int idx = gc.bid * NT + threadIdx.x; idx < n1 + n2; idx += gc.nb * NT) {
         if (idx < n1) {
@@ -1266,12 +1307,14 @@ __global__ __launch_bounds__(NT) void k_chain_equaliser(Lay l, const float* __re
     d_chain_equaliser(GridCtx{(int)blockIdx.x, (int)gridDim.x}, l, ws, g_k1, g_k2);
 }
 
-__device__ __forceinline__ void d_copy(const GridCtx gc, const float* __restrict__ src, float* __restrict__ dst, int n) {
-    for (int i = gc.bid * NT + threadIdx.x; i < n; i += gc.nb * NT) dst[i] = src[i];
+// accumulate != 0: dst += src (a gradient the caller never resets, lib/real_equalization.py:1169-1178, :1356-1364)
+__device__ __forceinline__ void d_copy(const GridCtx gc, const float* __restrict__ src, float* __restrict__ dst, int n,
+                                       int accumulate = 0) {
+    for (int i = gc.bid * NT + threadIdx.x; i < n; i += gc.nb * NT) dst[i] = accumulate ? dst[i] + src[i] : src[i];
 }
 
-__global__ __launch_bounds__(NT) void k_copy(const float* __restrict__ src, float* __restrict__ dst, int n) {
-    d_copy(GridCtx{(int)blockIdx.x, (int)gridDim.x}, src, dst, n);
+__global__ __launch_bounds__(NT) void k_copy(const float* __restrict__ src, float* __restrict__ dst, int n, int accumulate) {
+    d_copy(GridCtx{(int)blockIdx.x, (int)gridDim.x}, src, dst, n, accumulate);
 }
 
 __device__ __forceinline__ void d_adam(const GridCtx gc, int64_t n, float* __restrict__ p, const float* __restrict__ g,
@@ -1376,7 +1419,7 @@ __global__ __launch_bounds__(NT) void k_fit_persistent(Lay l, v2vae_fit_args a, 
         d_chain_channel(one, l, ws, scal, nullptr, g, g + n0);
         d_sum_records_all(ws + l.o_part_sym, l.rec_sym, l.nblk_sym, ws + l.o_sumstage, ws + l.o_tot_sym);
         __syncthreads();
-        d_copy(one, ws + l.o_tot_sym, g + n0 + n1 + n2 + n3, l.rec_sym);
+        d_copy(one, ws + l.o_tot_sym, g + n0 + n1 + n2 + n3, l.rec_sym, a.accumulate_scaling_grad);
         d_sum_records_all(ws + l.o_part_eq, l.rec_eq, l.nblk_eq, ws + l.o_sumstage, ws + l.o_tot_eq);
         __syncthreads();
         d_chain_equaliser(one, l, ws, g + n0 + n1, n3 ? g + n0 + n1 + n2 : nullptr);
@@ -1627,7 +1670,8 @@ int v2vae_finish_grads(const v2vae_problem* p, void* ws, const double* scal, con
         hipLaunchKernelGGL(k_chain_channel, dim3((n + NT - 1) / NT), dim3(NT), 0, st, l, (const float*)w, scal, grad_scale, g_h1, g_h2);
     }
     if ((which & 2) && g_scaling)
-        hipLaunchKernelGGL(k_copy, dim3((l.rec_sym + NT - 1) / NT), dim3(NT), 0, st, (const float*)(w + l.o_tot_sym), g_scaling, l.rec_sym);
+        hipLaunchKernelGGL(k_copy, dim3((l.rec_sym + NT - 1) / NT), dim3(NT), 0, st, (const float*)(w + l.o_tot_sym), g_scaling, l.rec_sym,
+                           (which & 8) ? 1 : 0);
     if ((which & 4) && l.use_eqcx) {
         launch_chain_equaliser_cx(l, w, g_k1, g_k2, st);
     } else if (which & 4) {
@@ -1654,7 +1698,7 @@ int v2vae_adam_amsgrad(int64_t n, float* params, const float* grads, float* m, f
 
 void v2vae_pack_sizes(const v2vae_problem* p, int64_t out[5]) {
     out[0] = (int64_t)p->ns * p->L;
-    out[1] = (int64_t)p->ns * p->L * p->L;
+    out[1] = p->mode == 2 ? (int64_t)p->L : p->mode == 3 ? 2 : (int64_t)p->ns * p->L * p->L;
     out[2] = (int64_t)p->ns * p->l1;
     out[3] = (int64_t)p->ns * p->l2 * p->l2;
     out[4] = (int64_t)p->ns * p->C;
@@ -1683,7 +1727,7 @@ int v2vae_train_step(const v2vae_problem* p, const v2vae_train_args* a, void* st
     }
     if ((rc = v2vae_sym_bwd(p, a->xhat, a->levels, a->prior, sc, a->noise_var, a->scal, nullptr, a->ws, a->gxhat, stream))) return rc;
     if ((rc = v2vae_eq_bwd(p, a->y, a->gxhat, a->ws, stream))) return rc;
-    if ((rc = v2vae_finish_grads(p, a->ws, a->scal, nullptr, 7, g, g + n[0], g + n[0] + n[1], n[3] ? g + n[0] + n[1] + n[2] : nullptr,
+    if ((rc = v2vae_finish_grads(p, a->ws, a->scal, nullptr, a->accumulate_scaling_grad ? 15 : 7, g, g + n[0], g + n[0] + n[1], n[3] ? g + n[0] + n[1] + n[2] : nullptr,
                                  g + n[0] + n[1] + n[2] + n[3], stream))) return rc;
     const int64_t nadam = n[0] + n[1] + n[2] + n[3] + (a->learn_scaling ? n[4] : 0);
     int64_t first = 0;

@@ -32,6 +32,10 @@ constexpr int CX_MAXLAG = 48;        // lagged products kept for sum s s^T (larg
 
 struct Lay {
     int ns, mode, S, l1, pad1, l2, L, C;
+    // channel model of the real path: 0 full second-order kernel h2 [L][L]; 1 memory polynomial (h2 [L] weighs x^2 per tap:
+    // diagonal second-order kernel); 2 Hammerstein (one filter h [L] on alpha1 x + alpha2 x^2; the h2 section is
+    // [alpha1, alpha2]).  1 and 2 run the same kernels on tables built with a diagonal kernel.
+    int chan;
     int64_t n_glob, y_lo, y_len, sym_lo, sym_cnt, own_lo, own_cnt;
     int64_t y_stride;  // floats between the ns sample streams (y_len unless a batch is a slice of a longer sequence)
     int pre;                 // (L-1)/2: y' = y[pre + n]
@@ -63,6 +67,7 @@ struct Lay {
     int rec_elbo, rec_eq, rec_sym;
     // workspace offsets in floats
     int64_t o_eqK1, o_eqK2, o_h1c, o_Hc, o_HHc, o_dc, o_dqc, o_mom, o_gmom;
+    int64_t o_chanraw;       // chan != 0: copy of the raw channel sections [h1 (L) | h2 section] for the chain rule
     int64_t o_part_elbo, o_part_eq, o_part_sym, o_tot_elbo, o_tot_eq, o_tot_sym;
     int64_t o_Epart, o_KLpart;  // doubles, offsets still in floats (8-byte aligned)
     int64_t total_floats;

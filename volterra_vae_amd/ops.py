@@ -36,10 +36,11 @@ class Plan:
     """Geometry + workspace for one (batch length, model shape, owned slice) combination."""
 
     def __init__(self, *, ns, sps, l1, pad1, l2, L, C_levels, n_glob, device,
-                 y_lo=0, y_len=None, sym_lo=0, sym_cnt=None, own_lo=None, own_cnt=None):
+                 y_lo=0, y_len=None, sym_lo=0, sym_cnt=None, own_lo=None, own_cnt=None, mode=None):
         b_glob = n_glob // sps
         p = Problem()
-        p.ns, p.mode, p.sps, p.l1, p.pad1, p.l2, p.L, p.C = ns, (0 if ns == 1 else 1), sps, l1, pad1, l2, L, C_levels
+        mode = (0 if ns == 1 else 1) if mode is None else mode  # 2 / 3: memory-polynomial / Hammerstein channel (real)
+        p.ns, p.mode, p.sps, p.l1, p.pad1, p.l2, p.L, p.C = ns, mode, sps, l1, pad1, l2, L, C_levels
         p.n_glob, p.y_lo = n_glob, y_lo
         p.y_len = n_glob if y_len is None else y_len
         p.sym_lo = sym_lo
@@ -109,7 +110,8 @@ class Plan:
 
     # --- whole fused step ------------------------------------------------------------------
     def train_step(self, *, y, levels, prior, params, grads, adam_m, adam_v, adam_vmax, noise_var, xhat, loss_out,
-                   lr, step, beta1=0.9, beta2=0.999, eps=1e-8, learn_scaling=True, adaptive_noise=True, freeze_h2=False):
+                   lr, step, beta1=0.9, beta2=0.999, eps=1e-8, learn_scaling=True, adaptive_noise=True, freeze_h2=False,
+                   accumulate_scaling_grad=False):
         a = TrainArgs()
         a.y, a.levels, a.prior = y.data_ptr(), levels.data_ptr(), prior.data_ptr()
         a.params, a.grads = params.data_ptr(), grads.data_ptr()
@@ -119,6 +121,7 @@ class Plan:
         a.loss_out = 0 if loss_out is None else loss_out.data_ptr()
         a.lr, a.beta1, a.beta2, a.eps, a.step = lr, beta1, beta2, eps, step
         a.learn_scaling, a.adaptive_noise, a.freeze_h2 = int(learn_scaling), int(adaptive_noise), int(freeze_h2)
+        a.accumulate_scaling_grad = int(accumulate_scaling_grad)
         check(lib.v2vae_train_step(C.byref(self.p), C.byref(a), _stream()), "v2vae_train_step")
 
 
@@ -144,9 +147,10 @@ class PersistentFit:
     (one workgroup per model): the mini-batch loop of lib/real_equalization.py:482-502 without a launch or a
     host round trip per batch.  All state tensors carry a leading model dimension."""
 
-    def __init__(self, *, ns, sps, l1, pad1, l2, L, C_levels, batch_symbols, n_models, device):
+    def __init__(self, *, ns, sps, l1, pad1, l2, L, C_levels, batch_symbols, n_models, device, mode=None):
         p = Problem()
-        p.ns, p.mode, p.sps, p.l1, p.pad1, p.l2, p.L, p.C = ns, (0 if ns == 1 else 1), sps, l1, pad1, l2, L, C_levels
+        mode = (0 if ns == 1 else 1) if mode is None else mode
+        p.ns, p.mode, p.sps, p.l1, p.pad1, p.l2, p.L, p.C = ns, mode, sps, l1, pad1, l2, L, C_levels
         p.n_glob = p.y_len = batch_symbols * sps
         p.y_lo = p.sym_lo = p.own_lo = 0
         p.sym_cnt = p.own_cnt = batch_symbols
@@ -165,7 +169,7 @@ class PersistentFit:
 
     def run(self, *, y, levels, prior, params, grads, adam_m, adam_v, adam_vmax, noise_var, lrs, step0=0,
             y_eq=None, loss_curve=None, beta1=0.9, beta2=0.999, eps=1e-8, learn_scaling=True, adaptive_noise=True,
-            freeze_h2=False):
+            freeze_h2=False, accumulate_scaling_grad=False):
         """y: [ns, T] (shared by all models) or [n_models, ns, T], T >= n_batches * B * sps; lrs: one learning
         rate per batch (its length is the number of batches); params & co: [n_models, pack]."""
         nb = len(lrs)
@@ -203,6 +207,7 @@ class PersistentFit:
         a.beta1, a.beta2, a.eps = beta1, beta2, eps
         a.n_models, a.n_batches = self.n_models, nb
         a.learn_scaling, a.adaptive_noise, a.freeze_h2 = int(learn_scaling), int(adaptive_noise), int(freeze_h2)
+        a.accumulate_scaling_grad = int(accumulate_scaling_grad)
         check(lib.v2vae_fit_persistent(C.byref(p), C.byref(a), _stream()), "v2vae_fit_persistent")
         self._keep = sched  # the launch is asynchronous: keep the schedule alive until the next call
 

@@ -160,7 +160,8 @@ class VAESecondVolterraForward(GenericTorchBlindProbabilisticEqualizer):
         self.constellation_size = C = len(self.constellation)
         self._eq_sizes = self._equaliser_sizes(**equaliser_kwargs)  # (l1, l2)
         l1, l2 = self._eq_sizes
-        n = [L, L * L, l1, l2 * l2, C]
+        h2_shape = self._channel_h2_shape(L)
+        n = [L, int(np.prod(h2_shape)), l1, l2 * l2, C]
         o = np.cumsum([0] + n)
         self._pack = torch.zeros(int(o[-1]), dtype=self.dtype, device=self.torch_device)
         self._sections = [(int(o[i]), n[i]) for i in range(5)]
@@ -169,7 +170,7 @@ class VAESecondVolterraForward(GenericTorchBlindProbabilisticEqualizer):
         self.channel_h1 = self._pack[o[0]:o[1]]
         self.channel_h1.data[L // 2] = 1.0
         self.channel_h1.requires_grad = True
-        self.channel_h2 = self._pack[o[1]:o[2]].view(L, L)
+        self.channel_h2 = self._pack[o[1]:o[2]].view(*h2_shape)
         self.channel_h2.requires_grad = True
 
         # equaliser (:764)
@@ -204,6 +205,12 @@ class VAESecondVolterraForward(GenericTorchBlindProbabilisticEqualizer):
             self._noise_var[0] = float(value) if not torch.is_tensor(value) else value.detach().to(self._noise_var)
 
     # ---- plumbing
+    _channel_mode = None              # C-ABI `mode` of the channel model (None: 0, full second-order kernel)
+    _accumulate_scaling_grad = False  # True where the reference never resets the noise-scaling gradient
+
+    def _channel_h2_shape(self, L):
+        return (L, L)
+
     def _equaliser_sizes(self, **equaliser_kwargs):
         raise NotImplementedError
 
@@ -216,7 +223,7 @@ class VAESecondVolterraForward(GenericTorchBlindProbabilisticEqualizer):
             l1, l2 = self._eq_sizes
             self._plans[n_samples] = Plan(ns=1, sps=self.samples_per_symbol, l1=l1, pad1=self._pad1(), l2=l2,
                                           L=self.channel_memory, C_levels=self.constellation_size, n_glob=n_samples,
-                                          device=self.torch_device)
+                                          device=self.torch_device, mode=self._channel_mode)
         return self._plans[n_samples]
 
     def _levels2d(self):
@@ -227,7 +234,7 @@ class VAESecondVolterraForward(GenericTorchBlindProbabilisticEqualizer):
         offsets = {}
         for g in groups:
             g["params"] = list(g["params"]) if not torch.is_tensor(g["params"]) else [g["params"]]
-        named = {"channel_h1": 0, "channel_filter": 0, "channel_h2": 1, "noise_scale": 4}
+        named = {"channel_h1": 0, "channel_filter": 0, "channel_h": 0, "channel_h2": 1, "noise_scale": 4}
         for g in groups:
             if g["name"] == "equaliser":
                 s = self._sections[2][0]
@@ -235,7 +242,7 @@ class VAESecondVolterraForward(GenericTorchBlindProbabilisticEqualizer):
                     offsets[id(p)] = (s, p.numel())
                     s += p.numel()
             else:
-                sec = self._sections[named[g["name"]]]
+                sec = self._sections[named[g["name"]]] if g["name"] in named else self._extra_sections()[g["name"]]
                 offsets[id(g["params"][0])] = sec
         self.optimizer = PackedAdamAMSGrad(groups, self._pack, offsets, lr=self.learning_rate)
 
@@ -272,12 +279,18 @@ class VAESecondVolterraForward(GenericTorchBlindProbabilisticEqualizer):
         n = y.shape[-1]
         plan = self._plan(n)
         loss, E = ElboLossFn.apply(plan, xhat.reshape(1, -1), y.reshape(1, -1).to(self.dtype).contiguous(), self.channel_h1,
-                                   self.channel_h2, self.noise_scaling.view(1, -1), self._noise_var,
+                                   self._h2_argument(), self.noise_scaling.view(1, -1), self._noise_var,
                                    self._levels2d(), self.constellation_prior.view(1, -1).contiguous())
         if self.adaptive_noise_variance:
             with torch.no_grad():
                 self._noise_var[0] = E / (n - self.channel_memory + 1)
         return loss
+
+    def _h2_argument(self):
+        return self.channel_h2
+
+    def _extra_sections(self):
+        return {}
 
     def _update_model(self, loss):
         loss.backward(retain_graph=True)
@@ -302,7 +315,8 @@ class VAESecondVolterraForward(GenericTorchBlindProbabilisticEqualizer):
             try:
                 self._plans[key] = PersistentFit(ns=1, sps=self.samples_per_symbol, l1=l1, pad1=self._pad1(), l2=l2,
                                                  L=self.channel_memory, C_levels=self.constellation_size,
-                                                 batch_symbols=B, n_models=1, device=self.torch_device)
+                                                 batch_symbols=B, n_models=1, device=self.torch_device,
+                                                 mode=self._channel_mode)
             except V2VAEError:
                 self._plans[key] = None
         return self._plans[key]
@@ -322,6 +336,13 @@ class VAESecondVolterraForward(GenericTorchBlindProbabilisticEqualizer):
         opt = self.optimizer
         opt._opt_called = True  # the fused step below is the optimizer step
         levels, prior = self._levels2d(), self.constellation_prior.view(1, -1).contiguous()
+        acc = self._accumulate_scaling_grad and self.learnable_noise_scaling
+        if acc:  # the running gradient sum lives in noise_scaling.grad between calls, as in the reference
+            s0, nsc = self._sections[4]
+            if self.noise_scaling.grad is None:
+                opt.flat_grad[s0:s0 + nsc].zero_()
+            else:
+                opt.flat_grad[s0:s0 + nsc].copy_(self.noise_scaling.grad)
         pf = None
         if self.persistent_fit is not False and n_batches and B <= self.PERSISTENT_MAX_BATCH:
             pf = self._persistent(B)
@@ -339,7 +360,9 @@ class VAESecondVolterraForward(GenericTorchBlindProbabilisticEqualizer):
                    adam_m=opt.exp_avg.view(1, -1), adam_v=opt.exp_avg_sq.view(1, -1), adam_vmax=opt.max_exp_avg_sq.view(1, -1),
                    noise_var=self._noise_var, lrs=lrs, step0=opt.step_count, y_eq=yq, loss_curve=losses[:n_batches].view(1, -1),
                    learn_scaling=self.learnable_noise_scaling, adaptive_noise=self.adaptive_noise_variance,
-                   freeze_h2=self._freeze_h2)
+                   freeze_h2=self._freeze_h2, accumulate_scaling_grad=acc)
+            if acc:
+                self.noise_scaling.grad = opt.flat_grad[s0:s0 + nsc].clone()
             opt.step_count += n_batches
             y_eq[:n_batches * B] = yq.view(-1)
             loss_curve = losses[:n_batches].cpu().numpy().astype(np.float64)
@@ -355,12 +378,14 @@ class VAESecondVolterraForward(GenericTorchBlindProbabilisticEqualizer):
                             adam_v=opt.exp_avg_sq, adam_vmax=opt.max_exp_avg_sq, noise_var=self._noise_var,
                             xhat=y_eq[n * B:(n + 1) * B], loss_out=losses[n:n + 1], lr=lr_now, step=opt.step_count,
                             learn_scaling=self.learnable_noise_scaling, adaptive_noise=self.adaptive_noise_variance,
-                            freeze_h2=self._freeze_h2)
+                            freeze_h2=self._freeze_h2, accumulate_scaling_grad=acc)
             if n % self.loss_print_interval == 0:
                 lrprint = lr_schedule.get_last_lr()[-1] if self.lr_schedule else self.learning_rate
                 print(f"Batch {n}, Loss: {losses[n].item():.3f} (LR: {lrprint:.3e})")
             if lr_schedule:
                 lr_schedule.step()
+        if acc and n_batches:
+            self.noise_scaling.grad = opt.flat_grad[s0:s0 + nsc].clone()
         loss_curve = losses[:n_batches].cpu().numpy().astype(np.float64)
         return y_eq.cpu().numpy(), loss_curve
 
@@ -550,3 +575,151 @@ class SecondVolterraVAE(VAELinearForward):
 
     def __repr__(self) -> str:
         return "SecondVolterraVAE"
+
+
+class VAEMemoryPolynomialForward(VAESecondVolterraForward):
+    """Blind VAE equaliser with a memory-polynomial channel model y = h1 * x + h2 * x^2 (lib/real_equalization.py:1224-1384;
+    ELBO :1304-1354).  That model is the second-order Volterra one with the DIAGONAL kernel diag(channel_h2), so it runs on
+    the same kernels (C-ABI mode 2); `channel_h2` is the [L] vector of the reference."""
+    _channel_mode = 2
+    _accumulate_scaling_grad = True  # :1356-1364 resets every gradient except noise_scaling's, which keeps accumulating
+
+    def _channel_h2_shape(self, L):
+        return (L,)
+
+    def get_parameters(self):
+        return [{'params': self.channel_h1, 'name': 'channel_h1'},
+                {'params': self.channel_h2, 'name': 'channel_h2'},
+                {'params': self.equaliser.parameters(), 'name': 'equaliser'},
+                {'params': self.noise_scaling, 'name': 'noise_scale'}]
+
+    def _update_model(self, loss):
+        loss.backward(retain_graph=True)
+        self.optimizer.step()
+        self.channel_h1.grad = None
+        self.channel_h2.grad = None
+        self.equaliser.zero_grad()
+
+    def print_model_parameters(self):
+        print("Equaliser")
+        self.equaliser.print_parameters()
+        print(f"Channel (h1): {self.channel_h1}")
+        print(f"Channel (h2): {self.channel_h2}")
+        print(f"Noise variance: {self.noise_variance}")
+
+
+class SecondVolterraMPVAE(VAEMemoryPolynomialForward):
+    """Memory-polynomial channel model, second-order Volterra equaliser (lib/real_equalization.py:1387-1410)."""
+
+    def __init__(self, channel_memory, learning_rate, constellation: np.ndarray, samples_per_symbol,
+                 batch_size, dtype=torch.float32, noise_variance=1, adaptive_noise_variance=True, noise_scaling=True,
+                 torch_device=None, lr_schedule='step', **equaliser_kwargs) -> None:
+        super().__init__(channel_memory, learning_rate, constellation, samples_per_symbol, batch_size, dtype, noise_variance,
+                         adaptive_noise_variance, noise_scaling, torch_device, lr_schedule, **equaliser_kwargs)
+
+    def _equaliser_sizes(self, **equaliser_kwargs):
+        return equaliser_kwargs['equaliser_n_lags1'], equaliser_kwargs['equaliser_n_lags2']
+
+    def initialize_equaliser(self, **equaliser_kwargs):
+        return SecondOrderVolterraSeries(n_lags1=equaliser_kwargs['equaliser_n_lags1'],
+                                         n_lags2=equaliser_kwargs['equaliser_n_lags2'],
+                                         samples_per_symbol=self.samples_per_symbol,
+                                         dtype=self.dtype, torch_device=self.torch_device, _storage=self._eq_storage)
+
+    def forward(self, y):
+        return self.equaliser.forward(y)
+
+    def __repr__(self) -> str:
+        return "SecondVolterraMPVAE"
+
+
+class VAEHammersteinForward(VAESecondVolterraForward):
+    """Blind VAE equaliser with a Hammerstein channel model y = h * (alpha_1 x + alpha_2 x^2)
+    (lib/real_equalization.py:1040-1199; ELBO :1117-1167): the memory polynomial with h1 = alpha_1 h, h2 = alpha_2 h, run on the
+    same kernels (C-ABI mode 3).  `channel_h`, `alpha_1`, `alpha_2` are views into the flat parameter pack."""
+    _channel_mode = 3
+    _accumulate_scaling_grad = True  # :1169-1178 never resets noise_scaling.grad
+
+    def __init__(self, channel_memory, learning_rate, constellation: np.ndarray,
+                 samples_per_symbol, batch_size, dtype=torch.float32, noise_variance=1.0,
+                 adaptive_noise_variance=True, torch_device=None, lr_schedule='step', **equaliser_kwargs) -> None:
+        super().__init__(channel_memory=channel_memory, learning_rate=learning_rate, constellation=constellation,
+                         samples_per_symbol=samples_per_symbol, batch_size=batch_size, dtype=dtype,
+                         noise_variance=noise_variance, adaptive_noise_variance=adaptive_noise_variance,
+                         noise_scaling=True, torch_device=torch_device, lr_schedule=lr_schedule, **equaliser_kwargs)
+        self.channel_h = self.channel_h1
+        s = self._sections[1][0]
+        self.channel_h2.requires_grad = False
+        self.alpha_1 = self._pack[s]       # 0-d views (:1057-1058)
+        self.alpha_2 = self._pack[s + 1]
+        self.alpha_1.data.fill_(1.0)
+        self.alpha_1.requires_grad = True
+        self.alpha_2.requires_grad = True
+
+    def _channel_h2_shape(self, L):
+        return (2,)
+
+    def _h2_argument(self):
+        return torch.stack((self.alpha_1, self.alpha_2))
+
+    def _extra_sections(self):
+        s = self._sections[1][0]
+        return {"alpha1": (s, 1), "alpha2": (s + 1, 1)}
+
+    def get_parameters(self):
+        return [{'params': self.channel_h, 'name': 'channel_h'},
+                {'params': self.alpha_1, 'name': 'alpha1'},
+                {'params': self.alpha_2, 'name': 'alpha2'},
+                {'params': self.equaliser.parameters(), 'name': 'equaliser'},
+                {'params': self.noise_scaling, 'name': 'noise_scale'}]
+
+    def _update_model(self, loss):
+        loss.backward(retain_graph=True)
+        self.optimizer.step()
+        self.channel_h.grad = None
+        self.alpha_1.grad = None
+        self.alpha_2.grad = None
+        self.equaliser.zero_grad()
+
+    def print_model_parameters(self):
+        print(f"Equaliser: {self.equaliser}")
+        print(f"Channel: {self.channel_h}")
+        print(f"Channel (non-linearity): {self.alpha_1:.4f}x + {self.alpha_2:.4f}x^2")
+        print(f"Noise variance: {self.noise_variance}")
+
+    def train_mode(self):
+        self.channel_h.requires_grad = True
+        self.alpha_1.requires_grad = True
+        self.alpha_2.requires_grad = True
+        self.equaliser.train()
+
+    def eval_mode(self):
+        self.channel_h.requires_grad = False
+        self.alpha_1.requires_grad = False
+        self.alpha_2.requires_grad = False
+        self.equaliser.eval()
+
+
+class SecondVolterraHVAE(VAEHammersteinForward):
+    """Hammerstein channel model, second-order Volterra equaliser (lib/real_equalization.py:1202-1221)."""
+
+    def __init__(self, channel_memory, learning_rate, constellation: np.ndarray, samples_per_symbol,
+                 batch_size, dtype=torch.float32, noise_variance=1, adaptive_noise_variance=True, torch_device=None,
+                 lr_schedule='step', **equaliser_kwargs) -> None:
+        super().__init__(channel_memory, learning_rate, constellation, samples_per_symbol, batch_size, dtype, noise_variance,
+                         adaptive_noise_variance, torch_device, lr_schedule, **equaliser_kwargs)
+
+    def _equaliser_sizes(self, **equaliser_kwargs):
+        return equaliser_kwargs['equaliser_n_lags1'], equaliser_kwargs['equaliser_n_lags2']
+
+    def initialize_equaliser(self, **equaliser_kwargs):
+        return SecondOrderVolterraSeries(n_lags1=equaliser_kwargs['equaliser_n_lags1'],
+                                         n_lags2=equaliser_kwargs['equaliser_n_lags2'],
+                                         samples_per_symbol=self.samples_per_symbol,
+                                         dtype=self.dtype, torch_device=self.torch_device, _storage=self._eq_storage)
+
+    def forward(self, y):
+        return self.equaliser.forward(y)
+
+    def __repr__(self) -> str:
+        return "SecondVolterraHVAE"
