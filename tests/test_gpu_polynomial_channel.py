@@ -83,16 +83,21 @@ def test_single_step_loss_and_gradients(case):
 
 
 @pytest.mark.parametrize("case", ["mpvae", "mpvae_fixed_scaling", "hvae"])
-@pytest.mark.parametrize("persistent", [False, True])
-def test_fit_trajectory_matches_reference(case, persistent):
-    """20 dependent steps incl. the reference's never-reset noise-scaling gradient; persistent=True runs the whole loop in
-    one launch of the stage-by-stage kernel."""
+@pytest.mark.parametrize("persistent", [False, None, "generic"])
+def test_fit_trajectory_matches_reference(case, persistent, monkeypatch):
+    """20 dependent steps incl. the reference's never-reset noise-scaling gradient: per-batch kernel sequence (False), the
+    default route (None: one launch of the on-chip kernel for these shapes) and one launch of the stage-by-stage kernel."""
+    if persistent == "generic":
+        monkeypatch.setenv("V2VAE_FORCE_GENERIC", "1")
+        persistent = True
     g32 = np.load(os.path.join(GOLDEN, f"poly_real_fit_{case}_f32.npz"))
     g64 = np.load(os.path.join(GOLDEN, f"poly_real_fit_{case}_f64.npz"))
     m = make(g32)
     m.persistent_fit = persistent
     m.initialize_optimizer()
     y_eq, loss_curve = m.fit(g32["rx"])
+    if persistent is None:
+        assert m._persistent(int(g32["B"])).on_chip
 
     def chk(ours, key, tol):
         own = rel(g32[key], g64[key])

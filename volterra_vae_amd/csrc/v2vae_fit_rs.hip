@@ -48,7 +48,7 @@ static inline int rs_rup(int x, int m) { return (x + m - 1) / m * m; }
 // Fills `o` and returns 1 if the shape fits this kernel.
 int rs_plan(const Lay& l, int64_t pack, RsOff* o) {
     if (getenv("V2VAE_FORCE_GENERIC")) return 0;
-    if (l.mode != 0 || l.chan != 0 || l.ns != 1 || l.LE > 8 || l.S > 4 || l.l2 > 31 || l.l1 > 64 || l.pad1 > RS_HL || l.C > MAX_C) return 0;
+    if (l.mode != 0 || l.ns != 1 || l.LE > 8 || l.S > 4 || l.l2 > 31 || l.l1 > 64 || l.pad1 > RS_HL || l.C > MAX_C) return 0;
     if (pack > RS_APT * RS_NT || l.b_glob > 4096 || l.n_glob > 8192) return 0;
     const int B = (int)l.b_glob, N = (int)l.n_glob;
     RsOff r{};
@@ -265,6 +265,9 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
     const float* levels = a.levels;
     const float* prior = a.prior;
     __syncthreads();
+    const int chan = l.chan;
+    // a noise-scaling gradient that is never reset (lib/real_equalization.py:1169-1178, :1356-1364) starts from the caller's sum
+    if (a.accumulate_scaling_grad && tid < n4) s_grad[n0 + n1 + n2 + n3 + tid] = a.grads[gbase + n0 + n1 + n2 + n3 + tid];
     const bool y_ahead = N <= RS_YPT * RS_NT;
     if (y_ahead)
         for (int i = tid; i < N; i += RS_NT) s_y[RS_HL + i] = ym[i];
@@ -300,17 +303,30 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
         for (int idx = tid; idx < S * 64; idx += RS_NT) {
             const int r = idx >> 6, k = (idx >> 3) & 7, j = idx & 7;
             const int ta = rs_tap(l, r, k), tb = rs_tap(l, r, j);
-            const float hv = (ta >= 0 && tb >= 0) ? p_h2[ta * L + tb] + p_h2[tb * L + ta] : 0.f;
+            float hv = 0.f;
+            if (ta >= 0 && tb >= 0) {
+                if (chan == 0) hv = p_h2[ta * L + tb] + p_h2[tb * L + ta];
+                else if (ta == tb) hv = chan == 2 ? p_h2[1] * p_h1[ta] : p_h2[ta];  // diagonal kernel of the polynomial channels
+            }
             s_H[idx] = hv;
             s_HH[idx] = hv * hv;
         }
         for (int idx = tid; idx < S * 8; idx += RS_NT) {
             const int r = idx >> 3, k = idx & 7;
             const int ta = rs_tap(l, r, k);
-            const float dg = ta >= 0 ? p_h2[ta * L + ta] : 0.f;
-            s_h1c[idx] = ta >= 0 ? p_h1[ta] : 0.f;
-            s_d[idx] = 2.f * dg;
-            s_dq[idx] = dg;  // lib/real_equalization.py:869 uses diag(h2), not diag(h2 + h2^T)
+            if (chan == 0) {
+                const float dg = ta >= 0 ? p_h2[ta * L + ta] : 0.f;
+                s_h1c[idx] = ta >= 0 ? p_h1[ta] : 0.f;
+                s_d[idx] = 2.f * dg;
+                s_dq[idx] = dg;  // lib/real_equalization.py:869 uses diag(h2), not diag(h2 + h2^T)
+            } else {
+                // memory polynomial (:1333-1334): a = h1, b = h2; Hammerstein (:1146-1147): a = alpha1 h, b = alpha2 h
+                const float av_ = ta < 0 ? 0.f : (chan == 2 ? p_h2[0] * p_h1[ta] : p_h1[ta]);
+                const float bv_ = ta < 0 ? 0.f : (chan == 2 ? p_h2[1] * p_h1[ta] : p_h2[ta]);
+                s_h1c[idx] = av_;
+                s_d[idx] = bv_;
+                s_dq[idx] = bv_;
+            }
         }
 
         RS_STAMP(2);
@@ -677,7 +693,24 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
                 r = rr;
                 k = (rr + L - 1 - t) / S;
             };
-            if (idx < n0) {
+            // polynomial channels: dE/da_t and dE/db_t (b = diagonal of the kernel, exact diagonal in the mean)
+            auto ga = [&](int t) { int r, k; compact(t, r, k); return s_gtot[r * RS_GREC + 64 + k]; };
+            auto gb = [&](int t) {
+                int r, k;
+                compact(t, r, k);
+                const float* T = s_gtot + r * RS_GREC;
+                return 2.f * T[k * 8 + k] + 4.f * s_H[r * 64 + k * 8 + k] * s_P[r * 64 + k * 8 + k] + T[64 + 8 + k] + T[64 + 16 + k];
+            };
+            if (chan == 1) {
+                s_grad[idx] = lam * (idx < n0 ? ga(idx) : gb(idx - n0));
+            } else if (chan == 2) {
+                if (idx < n0) s_grad[idx] = lam * (p_h2[0] * ga(idx) + p_h2[1] * gb(idx));
+                else {
+                    float acc = 0.f;
+                    for (int t = 0; t < L; ++t) acc = fmaf(p_h1[t], idx == n0 ? ga(t) : gb(t), acc);
+                    s_grad[idx] = lam * acc;
+                }
+            } else if (idx < n0) {
                 int r, k;
                 compact(idx, r, k);
                 s_grad[idx] = lam * s_gtot[r * RS_GREC + 64 + k];
@@ -700,7 +733,7 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
         if (tid < C) {
             float s = 0.f;
             for (int w = 0; w < RS_NW; ++w) s += s_misc[w * MAX_C + tid];
-            s_grad[n0 + n1 + n2 + n3 + tid] = s;
+            s_grad[n0 + n1 + n2 + n3 + tid] = a.accumulate_scaling_grad ? s_grad[n0 + n1 + n2 + n3 + tid] + s : s;
         }
 
         RS_STAMP(9);
@@ -816,7 +849,7 @@ int fit_rs_applicable(const Lay& l, int64_t pack) {
 int launch_fit_rs(const Lay& l, const v2vae_fit_args* a, const int64_t n[5], hipStream_t st) {
     RsOff o;
     const int64_t pack = n[0] + n[1] + n[2] + n[3] + n[4];
-    if (!rs_plan(l, pack, &o) || a->accumulate_scaling_grad) return 0;  // gradients are overwritten per step in this kernel
+    if (!rs_plan(l, pack, &o)) return 0;
     const int lds = o.total * 4;
 #define V2VAE_LAUNCH_RS(CB)                                                                                             \
     do {                                                                                                                \
