@@ -193,3 +193,30 @@ def test_complex_L65_shape_matches_oracle():
     for ours, ref in ((out["g"]["h1"], th1.grad), (out["g"]["h2"], th2.grad), (out["g"]["k1"], tk1.grad),
                       (out["g"]["k2"], tk2.grad), (out["g"]["sc"], tsc.grad)):
         assert rel(ours, ref) < TOL
+
+
+@pytest.mark.parametrize("l1,l2,S,B", [(33, 33, 2, 700), (9, 47, 1, 300), (63, 63, 2, 520), (65, 65, 2, 1100), (31, 95, 2, 600),
+                                       (95, 95, 1, 257)])
+def test_complex_long_equaliser_blocked_kernel_matches_oracle(l1, l2, S, B):
+    """31 < second-order lags <= 95: the blocked matrix-core equaliser (2 or 3 row blocks of 32 lags; first-order kernel
+    shorter than or as long as the second-order one; several tiles and a ragged last one) against the fp64 autograd oracle."""
+    from oracle import v2vae_oracle as orc
+    from volterra_vae_amd.ops import Plan
+    L, M = 9, 4
+    y, levels, prior, scaling, h1, h2, k1, k2 = _complex_inputs(11, L, S, l1, l2, B, M)
+    k2 *= 10.0 / l2
+    nv = 0.09
+    t = lambda a: torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    th1, th2, tk1, tk2, tsc = t(h1), t(h2), t(k1), t(k2), t(scaling)
+    ty = torch.tensor(y)
+    xr = orc.complex_equaliser(ty, tk1[0], tk1[1], tk2[0], tk2[1], S)
+    loss, E, kl = orc.complex_v2vae_loss(xr, ty, th1[0], th1[1], th2[0], th2[1], torch.tensor(levels), torch.tensor(prior),
+                                         torch.tensor(nv, dtype=torch.float64), tsc, S)
+    loss.backward()
+    plan = Plan(ns=2, sps=S, l1=l1, pad1=l1 // 2, l2=l2, L=L, C_levels=M, n_glob=B * S, device="cuda")
+    out = run_step(plan, dev(y), dev(h1), dev(h2), dev(k1), dev(k2), dev(levels), dev(prior), dev(scaling), dev(np.array([nv])))
+    assert rel(out["xhat"], xr.detach().numpy()) < TOL
+    assert abs(out["loss"] - float(loss.detach())) < TOL * abs(float(loss.detach()))
+    assert rel(out["g"]["k1"], tk1.grad) < TOL
+    assert rel(out["g"]["k2"], tk2.grad) < TOL
+    assert rel(out["g"]["h1"], th1.grad) < TOL

@@ -1,0 +1,306 @@
+// Complex second-order Volterra equaliser on the f32 matrix cores for LONG kernels (31 < l2 <= 95 lags), forward and
+// backward: the lag rows of v2vae_eq_cx.hip cut into NBL blocks of 32.
+//
+// xhat_b = sum_j k1[j] y[bS + j - p1] + Y_b^T K Y_b,  K = k2 + k2^T complex symmetric, Y_b[x] = y[bS + p2 - x]
+// (lib/torch_components.py:79-96 on complex samples).
+//
+// Forward: [Zr | Zi] = [Ya | Yb] . [[Kr, Ki], [-Ki, Kr]] with symbols on the lanes and lag rows in the accumulator
+// registers: 2 * NBL tiles of 32 rows per 32 symbols, all fed by the same B operand per k-step, so every k-step is 2 * NBL
+// independent v_mfma_f32_32x32x2_f32.  The constant A operands (the kernel table, up to 147 KB) stay in LDS for the whole
+// workgroup; row l2 of the table carries the first-order kernel.  xhat = Y^T Z is lane-local plus one exchange with lane ^ 32.
+//
+// Backward: with rho = g0 Ya + g1 Yb, sigma = g1 Ya - g0 Yb (g = dloss/dxhat) the gradient of the effective kernel is
+//     dKr = sum_b rho^T Ya + sigma^T Yb,   dKi = sum_b sigma^T Ya - rho^T Yb,
+// both SYMMETRIC in the lag pair, so only the NBL (NBL + 1) / 2 upper-triangular 32x32 blocks are accumulated (two MFMAs into
+// each of the two planes per block and k-step, two symbols per k-step).  A ones column at lag index l2 of the Ya operand (zero in
+// the Yb operand) yields the first-order gradient in the same products.
+//
+// Applies when mode = complex, l2 odd in (31, 95], l1 odd <= l2 and pad1 = l1 / 2.
+#include <hip/hip_runtime.h>
+
+#include "v2vae_cx_common.h"
+#include "v2vae_layout.h"
+
+namespace v2vae {
+
+__device__ __forceinline__ void eqcxb_load_tile(const Lay& l, const float* __restrict__ y, int64_t g0, float* tile) {
+    const int n = l.ns * l.tile_len;
+    for (int idx = threadIdx.x; idx < n; idx += NT) {
+        const int c = idx / l.tile_len, i = idx - c * l.tile_len;
+        const int64_t g = g0 + i;
+        float v = 0.f;
+        if (g >= 0 && g < l.n_glob) {
+            const int64_t loc = g - l.y_lo;
+            if (loc >= 0 && loc < l.y_len) v = y[(int64_t)c * l.y_stride + loc];
+        }
+        tile[idx] = v;
+    }
+}
+
+// A-operand table of the forward: tab[step][row block][plane (Zr, Zi)][64 lanes]
+__global__ __launch_bounds__(NT) void k_prep_eqcxb(Lay l, const float* __restrict__ k1, const float* __restrict__ k2,
+                                                   float* __restrict__ ws) {
+    const int l1 = l.l1, l2 = l.l2, p1 = l.pad1, p2 = l.p2, LK = l.eqcx_lk, NBL = l.eqcxb_nbl;
+    const float* k1r = k1;
+    const float* k1i = k1 + l1;
+    const float* k2r = k2;
+    const float* k2i = k2 + (size_t)l2 * l2;
+    const int n = l.eqcx_steps * NBL * 2 * 64;
+    for (int idx = blockIdx.x * NT + threadIdx.x; idx < n; idx += gridDim.x * NT) {
+        const int lane = idx & 63, plane = (idx >> 6) & 1, jb = (idx >> 7) % NBL, s = idx / (128 * NBL);
+        const int j = jb * 32 + (lane & 31), h = lane >> 5;
+        const int k = 2 * s + h, ck = k >= LK ? 1 : 0, x = k - ck * LK;  // stacked input lag (stream ck, lag x)
+        float v = 0.f;
+        if (x < l2) {
+            if (j < l2) {
+                const float kr = k2r[x * l2 + j] + k2r[j * l2 + x], ki = k2i[x * l2 + j] + k2i[j * l2 + x];
+                v = ck == 0 ? (plane == 0 ? kr : ki) : (plane == 0 ? -ki : kr);  // [[Kr, Ki], [-Ki, Kr]]
+            } else if (j == l2) {
+                const int jj = p1 + p2 - x;  // first-order tap that multiplies lag x
+                if (jj >= 0 && jj < l1) {
+                    const float ar = k1r[jj], ai = k1i[jj];
+                    v = ck == 0 ? (plane == 0 ? ar : ai) : (plane == 0 ? -ai : ar);
+                }
+            }
+        }
+        ws[l.o_eqcxbA + idx] = v;
+    }
+}
+
+template <int NBL>
+__global__ __launch_bounds__(NT) void k_eq_fwd_cxb(Lay l, const float* __restrict__ y, const float* __restrict__ ws,
+                                                   float* __restrict__ xhat) {
+    extern __shared__ float sm[];
+    float* tile = sm;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int bl = lane & 31, h = lane >> 5;
+    const int64_t b0 = l.sym_lo + (int64_t)blockIdx.x * EQ_TB;
+    eqcxb_load_tile(l, y, b0 * l.S - l.hl, tile);
+    const int steps = l.eqcx_steps, LK = l.eqcx_lk;
+    float* s_A = tile + ((l.ns * l.tile_len + 63) & ~63);
+    {
+        const float4* src = reinterpret_cast<const float4*>(ws + l.o_eqcxbA);
+        float4* dst = reinterpret_cast<float4*>(s_A);
+        for (int idx = tid; idx < steps * NBL * 32; idx += NT) dst[idx] = src[idx];
+    }
+    __syncthreads();
+    const float* tr = tile;
+    const float* ti = tile + l.tile_len;
+    const float* Al = s_A + lane;
+#pragma unroll 1
+    for (int sub = 0; sub < 2; ++sub) {
+        const int bloc = wv * 64 + sub * 32 + bl;           // symbol within the block tile
+        const int base = bloc * l.S + l.hl + l.p2;          // tile index of lag 0
+        f32x16 Z[NBL][2];
+#pragma unroll
+        for (int jb = 0; jb < NBL; ++jb)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { Z[jb][0][g] = 0.f; Z[jb][1][g] = 0.f; }
+        // stream 0 lags then stream 1 lags: k = 2 s + h runs over [0, 2 LK); LK is even, so a step never straddles the streams
+#pragma unroll 2
+        for (int s = 0; s < steps; ++s) {
+            const int k = 2 * s + h;
+            const int ck = k >= LK ? 1 : 0, x = k - ck * LK;
+            const float b = (ck ? ti : tr)[base - x];
+            const float* As = Al + (size_t)s * NBL * 128;
+#pragma unroll
+            for (int jb = 0; jb < NBL; ++jb) {
+                Z[jb][0] = MFMA32(As[jb * 128], b, Z[jb][0]);
+                Z[jb][1] = MFMA32(As[jb * 128 + 64], b, Z[jb][1]);
+            }
+        }
+        float re = 0.f, im = 0.f;
+#pragma unroll
+        for (int jb = 0; jb < NBL; ++jb)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int j = jb * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+                if (j < l.l2) {
+                    const float ya = tr[base - j], yb = ti[base - j];
+                    re += ya * Z[jb][0][g] - yb * Z[jb][1][g];
+                    im += ya * Z[jb][1][g] + yb * Z[jb][0][g];
+                } else if (j == l.l2) {
+                    re += Z[jb][0][g];
+                    im += Z[jb][1][g];
+                }
+            }
+        re += __shfl_xor(re, 32);
+        im += __shfl_xor(im, 32);
+        const int64_t b = b0 + bloc;
+        if (h == 0 && b < l.sym_lo + l.sym_cnt) {
+            xhat[b - l.sym_lo] = re;
+            xhat[l.sym_cnt + (b - l.sym_lo)] = im;
+        }
+    }
+}
+
+// upper-triangular block index of (ib <= jb)
+__host__ __device__ constexpr int eqcxb_blk(int nbl, int ib, int jb) { return ib * nbl - ib * (ib - 1) / 2 + (jb - ib); }
+
+template <int NBL>
+__global__ __launch_bounds__(NT) void k_eq_bwd_cxb(Lay l, const float* __restrict__ y, const float* __restrict__ gx,
+                                                   float* __restrict__ ws) {
+    constexpr int NBLK = NBL * (NBL + 1) / 2;
+    extern __shared__ float sm[];
+    float* tile = sm;
+    float* gt = tile + l.ns * l.tile_len;  // [2][EQ_TB]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    f32x16 G0[NBLK], G1[NBLK];
+#pragma unroll
+    for (int q = 0; q < NBLK; ++q)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) { G0[q][g] = 0.f; G1[q][g] = 0.f; }
+    const float* tr = tile;
+    const float* ti = tile + l.tile_len;
+    // lag index of this lane in every block; lags beyond l2 are clamped for the loads and masked in the column operands
+    int jc[NBL];
+    float mA[NBL], mB[NBL], oneA[NBL];
+#pragma unroll
+    for (int ib = 0; ib < NBL; ++ib) {
+        const int a = ib * 32 + j;
+        jc[ib] = a <= l.l2 ? a : l.l2;
+        mA[ib] = a < l.l2 ? 1.f : 0.f;       // Ya column: the lag itself below l2 ...
+        oneA[ib] = a == l.l2 ? 1.f : 0.f;    // ... a ones column at l2 (first-order gradient), zero beyond
+        mB[ib] = a < l.l2 ? 1.f : 0.f;       // Yb column: zero from l2 on
+    }
+    for (int t = blockIdx.x; t < l.ntile_eq; t += gridDim.x) {
+        const int64_t b0 = l.own_lo + (int64_t)t * EQ_TB;
+        const int64_t rem = l.own_lo + l.own_cnt - b0;
+        const int nbs = rem < EQ_TB ? (int)rem : EQ_TB;
+        __syncthreads();
+        eqcxb_load_tile(l, y, b0 * l.S - l.hl, tile);
+        for (int idx = tid; idx < 2 * EQ_TB; idx += NT) {
+            const int o = idx / EQ_TB, i = idx - o * EQ_TB;
+            gt[idx] = i < nbs ? gx[(int64_t)o * l.sym_cnt + (b0 + i - l.sym_lo)] : 0.f;
+        }
+        __syncthreads();
+        const int wbase = wv * 64;
+#pragma unroll 2
+        for (int s = 0; s < 32; ++s) {
+            const int bloc = wbase + 2 * s + h;
+            const int base = bloc * l.S + l.hl + l.p2;
+            const float g0 = gt[bloc], g1 = gt[EQ_TB + bloc];
+            float rho[NBL], sig[NBL], nrho[NBL], ca[NBL], cb[NBL];
+#pragma unroll
+            for (int ib = 0; ib < NBL; ++ib) {
+                const float xa = tr[base - jc[ib]], xb = ti[base - jc[ib]];
+                rho[ib] = g0 * xa + g1 * xb;
+                sig[ib] = g1 * xa - g0 * xb;
+                nrho[ib] = -rho[ib];
+                ca[ib] = fmaf(xa, mA[ib], oneA[ib]);
+                cb[ib] = xb * mB[ib];
+            }
+#pragma unroll
+            for (int ib = 0; ib < NBL; ++ib)
+#pragma unroll
+                for (int jb = ib; jb < NBL; ++jb) {
+                    const int q = eqcxb_blk(NBL, ib, jb);
+                    G0[q] = MFMA32(rho[ib], ca[jb], G0[q]);
+                    G1[q] = MFMA32(sig[ib], ca[jb], G1[q]);
+                    G0[q] = MFMA32(sig[ib], cb[jb], G0[q]);
+                    G1[q] = MFMA32(nrho[ib], cb[jb], G1[q]);
+                }
+        }
+    }
+    // fixed-order reduction of the four waves through LDS, then one record per block: [plane][block][32][32]
+    __syncthreads();
+    float* img = sm;
+    for (int w = 0; w < 4; ++w) {
+        if (wv == w) {
+#pragma unroll
+            for (int q = 0; q < NBLK; ++q)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int e = q * 1024 + ((g & 3) + 8 * (g >> 2) + 4 * h) * 32 + j;
+                    if (w == 0) {
+                        img[e] = G0[q][g]; img[NBLK * 1024 + e] = G1[q][g];
+                    } else {
+                        img[e] += G0[q][g]; img[NBLK * 1024 + e] += G1[q][g];
+                    }
+                }
+        }
+        __syncthreads();
+    }
+    float* rec = ws + l.o_part_eqcxb + (size_t)blockIdx.x * (2 * NBLK * 1024);
+    for (int e = tid; e < 2 * NBLK * 1024; e += NT) rec[e] = img[e];
+}
+
+__global__ __launch_bounds__(NT) void k_chain_equaliser_cxb(Lay l, const float* __restrict__ ws, float* __restrict__ g_k1,
+                                                            float* __restrict__ g_k2) {
+    const float* T = ws + l.o_tot_eqcxb;
+    const int l1 = l.l1, l2 = l.l2, NBL = l.eqcxb_nbl, NBLK = NBL * (NBL + 1) / 2;
+    const int n1 = 2 * l1, n2 = 2 * l2 * l2;
+    auto GK = [&](int p, int a, int b) {  // d loss / d K (effective symmetric kernel) of plane p, any (a, b)
+        if (a > b) { const int t = a; a = b; b = t; }
+        const int ib = a >> 5, jb = b >> 5;
+        return T[((size_t)p * NBLK + eqcxb_blk(NBL, ib, jb)) * 1024 + (a & 31) * 32 + (b & 31)];
+    };
+    for (int idx = blockIdx.x * NT + threadIdx.x; idx < n1 + n2; idx += gridDim.x * NT) {
+        if (idx < n1) {
+            if (!g_k1) continue;
+            const int p = idx / l1, jj = idx - p * l1;
+            const int x = l.pad1 + l.p2 - jj;  // lag row that first-order tap jj multiplies (x < l2: always above the ones column)
+            g_k1[idx] = T[((size_t)p * NBLK + eqcxb_blk(NBL, x >> 5, l2 >> 5)) * 1024 + (x & 31) * 32 + (l2 & 31)];
+        } else {
+            if (!g_k2) continue;
+            const int e = idx - n1;
+            const int p = e / (l2 * l2), rem = e - p * l2 * l2;
+            const int a = rem / l2, b = rem - a * l2;
+            // inside a diagonal block both orientations were accumulated; across blocks the symmetric partner is the same entry
+            const bool same = (a >> 5) == (b >> 5);
+            const float v = same ? T[((size_t)p * NBLK + eqcxb_blk(NBL, a >> 5, a >> 5)) * 1024 + (a & 31) * 32 + (b & 31)] +
+                                       T[((size_t)p * NBLK + eqcxb_blk(NBL, a >> 5, a >> 5)) * 1024 + (b & 31) * 32 + (a & 31)]
+                                 : 2.f * GK(p, a, b);
+            g_k2[e] = v;
+        }
+    }
+}
+
+int launch_prep_eqcxb(const Lay& l, const float* k1, const float* k2, float* ws, hipStream_t st) {
+    hipLaunchKernelGGL(k_prep_eqcxb, dim3(32), dim3(NT), 0, st, l, k1, k2, ws);
+    return V2VAE_OK;
+}
+
+template <typename K>
+static int eqcxb_allow_lds(K kernel, int bytes) {
+    if (bytes <= 64 * 1024) return V2VAE_OK;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess
+               ? V2VAE_OK : V2VAE_ELAUNCH;
+}
+
+int launch_eq_fwd_cxb(const Lay& l, const float* y, const float* ws, float* xhat, hipStream_t st) {
+    const int nblk = (int)((l.sym_cnt + EQ_TB - 1) / EQ_TB);
+    int rc;
+#define V2VAE_LAUNCH_EQF(NBL)                                                                                     \
+    do {                                                                                                          \
+        if ((rc = eqcxb_allow_lds(k_eq_fwd_cxb<NBL>, l.lds_eqcxb_fwd))) return rc;                                \
+        hipLaunchKernelGGL(k_eq_fwd_cxb<NBL>, dim3(nblk), dim3(NT), l.lds_eqcxb_fwd, st, l, y, ws, xhat);          \
+    } while (0)
+    if (l.eqcxb_nbl == 2) V2VAE_LAUNCH_EQF(2);
+    else if (l.eqcxb_nbl == 3) V2VAE_LAUNCH_EQF(3);
+    else return V2VAE_ESIZE;
+#undef V2VAE_LAUNCH_EQF
+    return V2VAE_OK;
+}
+
+int launch_eq_bwd_cxb(const Lay& l, const float* y, const float* gx, float* ws, hipStream_t st) {
+    int rc;
+#define V2VAE_LAUNCH_EQB(NBL)                                                                                     \
+    do {                                                                                                          \
+        if ((rc = eqcxb_allow_lds(k_eq_bwd_cxb<NBL>, l.lds_eqcxb_bwd))) return rc;                                \
+        hipLaunchKernelGGL(k_eq_bwd_cxb<NBL>, dim3(l.nblk_eq), dim3(NT), l.lds_eqcxb_bwd, st, l, y, gx, ws);       \
+    } while (0)
+    if (l.eqcxb_nbl == 2) V2VAE_LAUNCH_EQB(2);
+    else if (l.eqcxb_nbl == 3) V2VAE_LAUNCH_EQB(3);
+    else return V2VAE_ESIZE;
+#undef V2VAE_LAUNCH_EQB
+    return V2VAE_OK;
+}
+
+void launch_chain_equaliser_cxb(const Lay& l, float* ws, float* g_k1, float* g_k2, hipStream_t st) {
+    const int n = 2 * l.l1 + 2 * l.l2 * l.l2;
+    hipLaunchKernelGGL(k_chain_equaliser_cxb, dim3((n + NT - 1) / NT), dim3(NT), 0, st, l, (const float*)ws, g_k1, g_k2);
+}
+
+}  // namespace v2vae

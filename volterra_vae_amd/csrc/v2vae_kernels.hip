@@ -104,6 +104,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
         if (l.ns * l.LTp > NT) generic_elbo_ok = 0;
     }
     // ---- equaliser tiling
+    int generic_eq_ok = 1;
     l.ntile_eq = (int)((l.own_cnt + EQ_TB - 1) / EQ_TB);
     l.nblk_eq = l.ntile_eq < MAX_BLOCKS ? l.ntile_eq : MAX_BLOCKS;
     {
@@ -112,7 +113,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
         if (l.nitems_eq == 0) { l.nchunk_eq = 1; l.maxi_eq = 1; }
         else if (l.nitems_eq <= NT) { l.nchunk_eq = NT / l.nitems_eq; l.maxi_eq = 1; }
         else { l.nchunk_eq = 1; l.maxi_eq = (l.nitems_eq + NT - 1) / NT; }
-        if (l.maxi_eq > 10) return V2VAE_ESIZE;
+        if (l.maxi_eq > 10) generic_eq_ok = 0;
         if (l.nchunk_eq > 16) l.nchunk_eq = 16;
         l.nk1 = l.ns * l.ns * l.l1;
         if (l.nk1 > 4 * NT) return V2VAE_ESIZE;
@@ -156,6 +157,18 @@ int make_layout(const v2vae_problem* p, Lay* out) {
                   getenv("V2VAE_FORCE_GENERIC") == nullptr) ? 1 : 0;
     l.eqcx_lk = (l.l2 + 2) & ~1;           // lags per stream, even and > l2 (the spare lag carries a zero coefficient)
     l.eqcx_steps = l.eqcx_lk;              // 2 streams * lk lags / 2 per MFMA step
+    // blocked variant for longer kernels
+    l.use_eqcxb = (l.mode == 1 && l.l2 > 31 && l.l2 <= 95 && (l.l1 & 1) && l.l1 <= l.l2 && l.pad1 == l.l1 / 2 &&
+                   getenv("V2VAE_FORCE_GENERIC") == nullptr) ? 1 : 0;
+    l.eqcxb_nbl = (l.l2 + 32) / 32;        // 32-row blocks holding lags 0 .. l2 (row l2 carries the first-order kernel)
+    l.eqcxb_rec = 2 * (l.eqcxb_nbl * (l.eqcxb_nbl + 1) / 2) * 1024;
+    l.lds_eqcxb_fwd = (int)((rup((int64_t)l.ns * l.tile_len, 64) + (int64_t)l.eqcx_steps * l.eqcxb_nbl * 128) * 4);
+    {
+        const int64_t a = (int64_t)l.ns * l.tile_len + 2 * EQ_TB, b = l.eqcxb_rec;
+        l.lds_eqcxb_bwd = (int)((a > b ? a : b) * 4);
+    }
+    if (l.use_eqcxb && l.lds_eqcxb_fwd > LDS_BUDGET) l.use_eqcxb = 0;
+    if (!generic_eq_ok && !l.use_eqcxb) return V2VAE_ESIZE;
     l.rec_elbo = l.S * rec_elbo_phase(l);
     l.rec_eq = l.ns * l.LT2p * l.LT2p + l.nk1;
     l.rec_sym = l.ns * l.C;
@@ -192,6 +205,9 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     l.o_eqcxA = take(l.use_eqcx ? (int64_t)2 * l.eqcx_steps * 64 : 0);
     l.o_part_eqcx = take(l.use_eqcx ? (int64_t)l.nblk_eq * 4096 : 0);
     l.o_tot_eqcx = take(l.use_eqcx ? 4096 : 0);
+    l.o_eqcxbA = take(l.use_eqcxb ? (int64_t)l.eqcx_steps * l.eqcxb_nbl * 128 : 0);
+    l.o_part_eqcxb = take(l.use_eqcxb ? (int64_t)l.nblk_eq * l.eqcxb_rec : 0);
+    l.o_tot_eqcxb = take(l.use_eqcxb ? l.eqcxb_rec : 0);
     {
         int64_t mx = l.rec_elbo;
         if (l.rec_eq > mx) mx = l.rec_eq;
@@ -199,6 +215,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
         if (l.S * CX_REC > mx) mx = l.S * CX_REC;
         if (l.use_cxb && l.S * l.cxb_rec > mx) mx = l.S * l.cxb_rec;
         if (4096 > mx) mx = 4096;
+        if (l.use_eqcxb && l.eqcxb_rec > mx) mx = l.eqcxb_rec;
         l.sumstage_stride = (int64_t)SUM_CHUNKS * mx;
         l.o_sumstage = take(3 * l.sumstage_stride);
     }
@@ -1509,6 +1526,7 @@ int v2vae_prep_tables(const v2vae_problem* p, const float* h1, const float* h2, 
     if (!ws || (!h1 && !k1) || (h1 && !h2) || (k1 && l.l2 > 0 && !k2)) return V2VAE_EINVAL;
     hipLaunchKernelGGL(k_prep_tables, dim3(16), dim3(NT), 0, (hipStream_t)stream, l, h1, h2, k1, k2, (float*)ws);
     if (k1 && l.use_eqcx) launch_prep_eqcx(l, k1, k2, (float*)ws, (hipStream_t)stream);
+    if (k1 && l.use_eqcxb) launch_prep_eqcxb(l, k1, k2, (float*)ws, (hipStream_t)stream);
     if (h1 && l.use_cxb) launch_prep_cxb(l, h1, h2, (float*)ws, (hipStream_t)stream);
     return launch_status();
 }
@@ -1521,6 +1539,10 @@ int v2vae_eq_fwd(const v2vae_problem* p, const float* y, const void* ws, float* 
     if (l.use_eqcx) {
         launch_eq_fwd_cx(l, y, (const float*)ws, xhat, (hipStream_t)stream);
         return launch_status();
+    }
+    if (l.use_eqcxb) {
+        rc = launch_eq_fwd_cxb(l, y, (const float*)ws, xhat, (hipStream_t)stream);
+        return rc ? rc : launch_status();
     }
     rc = allow_lds(k_eq_fwd, l.lds_eq);
     if (rc) return rc;
@@ -1630,6 +1652,10 @@ int v2vae_eq_bwd(const v2vae_problem* p, const float* y, const float* gxhat, voi
         launch_eq_bwd_cx(l, y, gxhat, (float*)ws, st);
         return launch_status();
     }
+    if (l.use_eqcxb) {
+        rc = launch_eq_bwd_cxb(l, y, gxhat, (float*)ws, st);
+        return rc ? rc : launch_status();
+    }
 #define V2VAE_LAUNCH_EQB(M)                                                                                   \
     do {                                                                                                      \
         rc = allow_lds(k_eq_bwd<M>, l.lds_eq);                                                                \
@@ -1659,6 +1685,7 @@ int v2vae_finish_grads(const v2vae_problem* p, void* ws, const double* scal, con
     else if (which & 1) sum_sets_add(ss, w + l.o_part_elbo, l.rec_elbo, l.nblk_elbo, stage, w + l.o_tot_elbo);
     if (which & 2) sum_sets_add(ss, w + l.o_part_sym, l.rec_sym, l.nblk_sym, stage + l.sumstage_stride, w + l.o_tot_sym);
     if ((which & 4) && l.use_eqcx) sum_sets_add(ss, w + l.o_part_eqcx, 4096, l.nblk_eq, stage + 2 * l.sumstage_stride, w + l.o_tot_eqcx);
+    else if ((which & 4) && l.use_eqcxb) sum_sets_add(ss, w + l.o_part_eqcxb, l.eqcxb_rec, l.nblk_eq, stage + 2 * l.sumstage_stride, w + l.o_tot_eqcxb);
     else if (which & 4) sum_sets_add(ss, w + l.o_part_eq, l.rec_eq, l.nblk_eq, stage + 2 * l.sumstage_stride, w + l.o_tot_eq);
     sum_sets_launch(ss, st);
     if ((which & 1) && l.use_cx) {
@@ -1674,6 +1701,8 @@ int v2vae_finish_grads(const v2vae_problem* p, void* ws, const double* scal, con
                            (which & 8) ? 1 : 0);
     if ((which & 4) && l.use_eqcx) {
         launch_chain_equaliser_cx(l, w, g_k1, g_k2, st);
+    } else if ((which & 4) && l.use_eqcxb) {
+        launch_chain_equaliser_cxb(l, w, g_k1, g_k2, st);
     } else if (which & 4) {
         const int n = l.ns * l.l1 + l.ns * l.l2 * l.l2;
         hipLaunchKernelGGL(k_chain_equaliser, dim3((n + NT - 1) / NT), dim3(NT), 0, st, l, (const float*)w, g_k1, g_k2);
@@ -1794,6 +1823,7 @@ int v2vae_fit_persistent(const v2vae_problem* p, const v2vae_fit_args* a, void* 
     l.use_cx = 0;
     l.use_cxb = 0;
     l.use_eqcx = 0;
+    l.use_eqcxb = 0;
     l.nblk_E = l.nblk_elbo;
     const int lds = l.lds_elbo > l.lds_eq ? l.lds_elbo : l.lds_eq;
 #define V2VAE_LAUNCH_FIT(CB, ME)                                                                                       \

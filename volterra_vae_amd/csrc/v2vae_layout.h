@@ -61,6 +61,9 @@ struct Lay {
     // matrix-core equaliser path
     int use_eqcx, eqcx_lk, eqcx_steps;
     int64_t o_eqcxA, o_part_eqcx, o_tot_eqcx;
+    // blocked matrix-core equaliser path (complex, 31 < l2 <= 95): lag rows in blocks of 32
+    int use_eqcxb, eqcxb_nbl, eqcxb_rec, lds_eqcxb_fwd, lds_eqcxb_bwd;
+    int64_t o_eqcxbA, o_part_eqcxb, o_tot_eqcxb;
     int64_t o_sumstage;      // 3 x [SUM_CHUNKS][largest record] staging of the two-stage record sums (one per record set)
     int64_t sumstage_stride; // floats between the three staging areas
     // record sizes of the per-workgroup partial sums (floats)
@@ -77,6 +80,10 @@ struct Lay {
 V2VAE_HD inline int rec_elbo_phase(const Lay& l) { return l.ns * l.LTp * l.LTp + l.LTp * l.LTp + l.ns * 3 * l.LTp; }
 
 int make_layout(const v2vae_problem* p, Lay* out);
+int launch_prep_eqcxb(const Lay& l, const float* k1, const float* k2, float* ws, hipStream_t st);
+int launch_eq_fwd_cxb(const Lay& l, const float* y, const float* ws, float* xhat, hipStream_t st);
+int launch_eq_bwd_cxb(const Lay& l, const float* y, const float* gx, float* ws, hipStream_t st);
+void launch_chain_equaliser_cxb(const Lay& l, float* ws, float* g_k1, float* g_k2, hipStream_t st);
 
 // v2vae_elbo_cx.hip
 int launch_elbo_cx(const Lay& l, const float* y, float* ws, hipStream_t st);
