@@ -158,6 +158,9 @@ def main():
     ap.add_argument("--channel-memory", type=int, default=25, help="L (65 with --order 64 = BASELINE.json configs[3] per GPU)")
     ap.add_argument("--lags", type=int, default=25, help="equaliser lags l1 = l2")
     ap.add_argument("--order", type=int, default=16, help="QAM order")
+    ap.add_argument("--data-source", choices=["host", "device"], default="host",
+                    help="host: numpy generator + one H2D copy (default, as in earlier rounds); device: the sequence is produced "
+                         "in HBM by v2vae_synth_channel (no host work; meant for the 2^26-symbol configuration)")
     ap.add_argument("--workload", choices=["train_step", "sweep"], default="train_step",
                     help="train_step: the headline configuration (default); sweep: 1024 independent real PAM-4 models, L=15")
     args = ap.parse_args()
@@ -197,9 +200,15 @@ def main():
     # synthetic nonlinear-ISI input for this rank's sample range (identical across ranks where ranges overlap)
     assert sr.y_lo % S == 0 or True
     s_lo, s_hi = sr.y_lo // S, -(-(sr.y_lo + sr.y_len) // S)
-    rx, _ = nonlinear_isi_range(20250321, qam_constellation(order), S, 16.0, s_lo, s_hi, b_glob)
-    rx = rx[sr.y_lo - s_lo * S: sr.y_lo - s_lo * S + sr.y_len]
-    y = torch.from_numpy(np.stack((rx.real, rx.imag))).to(torch.float32).to(dev).contiguous()
+    if args.data_source == "device":
+        from volterra_vae_amd.synth_device import nonlinear_isi_device
+        m_side = int(round(np.sqrt(order)))
+        yy = nonlinear_isi_device(20250321, np.arange(-(m_side - 1), m_side, 2), 2, S, 16.0, b_glob, s_lo, s_hi - s_lo, device=dev)
+        y = yy[:, sr.y_lo - s_lo * S: sr.y_lo - s_lo * S + sr.y_len].contiguous()
+    else:
+        rx, _ = nonlinear_isi_range(20250321, qam_constellation(order), S, 16.0, s_lo, s_hi, b_glob)
+        rx = rx[sr.y_lo - s_lo * S: sr.y_lo - s_lo * S + sr.y_len]
+        y = torch.from_numpy(np.stack((rx.real, rx.imag))).to(torch.float32).to(dev).contiguous()
 
     n = plan.sizes
     params = torch.zeros(sum(n), dtype=torch.float32, device=dev)
@@ -288,7 +297,7 @@ def main():
             "metric": "V2VAE train-step symbols/sec (fwd+bwd) at 1/2/4/8 MI355X; % of HBM/MFMA roofline",
             "value": b_glob * args.steps / elapsed, "unit": "symbols/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (generated on device)" if args.data_source == "device" else ""),
             "config": {"workload": f"complex {order}-QAM V2VAE train step, L={L}, l1=l2={l1}, sps=2, one batch of {world}x2^{args.log2_symbols} symbols, "
                                    "Adam-AMSGrad, random-init (dirac) kernels, synthetic Wiener-Hammerstein ISI at 16 dB",
                        "symbols_per_gpu": b_per_gpu, "parallelism": f"halo-sharded dp{world}" if world > 1 else "single GPU"},

@@ -223,6 +223,39 @@ int v2vae_fit_persistent(const v2vae_problem* p, const v2vae_fit_args* a, void* 
  * many models); negative = status code (shape not supported by either). */
 int v2vae_fit_persistent_kind(const v2vae_problem* p);
 
+/* Device-side synthetic channel (no counterpart function in the reference: its simulator, lib/data_generation.py:206-241 and
+ * :349-372, runs on the host with numpy; this produces the same kind of sequence directly in HBM).  Chain: uniform symbols
+ * (levels per axis) -> zero-stuffing to sps samples -> pulse -> fir1 -> w = poly1 z + poly2 z^2 (complex arithmetic for ns = 2)
+ * -> fir2 -> (. - mean) * inv_std -> + white Gaussian noise of standard deviation noise_std per stream.  Every stage is a
+ * 'same' convolution with zeros outside the global sequence of b_glob symbols.  All random numbers are functions of
+ * (seed, global index), so overlapping ranges produced by different ranks are identical. */
+typedef struct v2vae_synth_args {
+    int32_t ns;        /* 1 real PAM, 2 complex square QAM (independent I / Q levels) */
+    int32_t sps;       /* samples per symbol, 1..8 */
+    int32_t C;         /* levels per axis, <= 16 */
+    int32_t n_pulse;   /* odd, <= 65 */
+    int32_t n_fir1;    /* odd, <= 9 */
+    int32_t n_fir2;    /* odd, <= 9 */
+    float levels[16];
+    float pulse[65];
+    float fir1[9];
+    float fir2[9];
+    float poly1, poly2;
+    float mean[2];     /* subtracted per stream before scaling */
+    float inv_std;
+    float noise_std;   /* per stream; 0 = no noise */
+    uint64_t seed;
+    int64_t b_glob;    /* symbols of the whole sequence */
+    int64_t sym_lo;    /* first symbol produced */
+    int64_t sym_cnt;   /* symbols produced: y [ns][sym_cnt * sps], sym_idx [ns][sym_cnt] level indices (may be NULL) */
+} v2vae_synth_args;
+
+int v2vae_synth_channel(const v2vae_synth_args* a, float* y, int32_t* sym_idx, void* stream);
+
+/* The 64 random bits behind symbol (kind 0: high / low 32 bits pick the I / Q level) or noise sample (kind 1) `idx`;
+ * host function, for checkers. */
+uint64_t v2vae_synth_bits(uint64_t seed, uint64_t kind, uint64_t idx);
+
 /* Read-only views into the workspace for tests and tooling: float offsets (in floats from the
  * workspace base) of the per-symbol moments [ns][4][sym_cnt] and of dE/d(moments), same shape. */
 int64_t v2vae_ws_offset_moments(const v2vae_problem* p);

@@ -55,6 +55,14 @@ class FitArgs(C.Structure):
                 ("adaptive_noise", C.c_int32), ("freeze_h2", C.c_int32), ("accumulate_scaling_grad", C.c_int32)]
 
 
+class SynthArgs(C.Structure):
+    _fields_ = [("ns", C.c_int32), ("sps", C.c_int32), ("C", C.c_int32), ("n_pulse", C.c_int32), ("n_fir1", C.c_int32),
+                ("n_fir2", C.c_int32), ("levels", C.c_float * 16), ("pulse", C.c_float * 65), ("fir1", C.c_float * 9),
+                ("fir2", C.c_float * 9), ("poly1", C.c_float), ("poly2", C.c_float), ("mean", C.c_float * 2),
+                ("inv_std", C.c_float), ("noise_std", C.c_float), ("seed", C.c_uint64), ("b_glob", C.c_int64),
+                ("sym_lo", C.c_int64), ("sym_cnt", C.c_int64)]
+
+
 EXPORTS = {
     # name: (restype, argtypes)
     "v2vae_version": (C.c_char_p, []),
@@ -71,6 +79,8 @@ EXPORTS = {
     "v2vae_eq_bwd": (C.c_int, [C.POINTER(Problem)] + [C.c_void_p] * 4),
     "v2vae_finish_grads": (C.c_int, [C.POINTER(Problem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 6),
     "v2vae_adam_amsgrad": (C.c_int, [C.c_int64] + [C.c_void_p] * 5 + [C.c_float] * 4 + [C.c_int64] + [C.c_void_p] * 4),
+    "v2vae_synth_channel": (C.c_int, [C.POINTER(SynthArgs), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "v2vae_synth_bits": (C.c_uint64, [C.c_uint64, C.c_uint64, C.c_uint64]),
     "v2vae_decide": (C.c_int, [C.POINTER(Problem)] + [C.c_void_p] * 6),
     "v2vae_pack_sizes": (None, [C.POINTER(Problem), C.POINTER(C.c_int64 * 5)]),
     "v2vae_train_step": (C.c_int, [C.POINTER(Problem), C.POINTER(TrainArgs), C.c_void_p]),
