@@ -51,6 +51,22 @@ int main() {
     (void)hipMalloc(&out, 512 * 4 * 4); (void)hipMalloc(&cyc, 8);
     const int iters = 20000;
     const char* names[4] = {"mfma chain only (16 x 32x32x2 f32)", "valu only (256 fma)", "serial phases", "interleaved in program order"};
+    // full-chip run of the MFMA chain: does the shader clock hold under load?  (ticks are shader cycles)
+    for (int grid = 1; grid <= 1024; grid *= 4) {
+        hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        float* big; (void)hipMalloc(&big, (size_t)grid * 512 * 4);
+        for (int rep = 0; rep < 3; ++rep) {
+            if (rep == 2) (void)hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(k<0>, dim3(grid), dim3(256), 0, 0, big, cyc, 10 * iters);
+            if (rep == 2) (void)hipEventRecord(e1, 0);
+            (void)hipDeviceSynchronize();
+        }
+        float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
+        unsigned long long c; (void)hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+        printf("grid %4d x 4 waves, mfma chain only: %8.1f ticks/iter, %7.1f ns/iter -> %.2f ticks/ns\n", grid, (double)c / (10 * iters),
+               ms * 1e6 / (10 * iters), (double)c / (ms * 1e6));
+        (void)hipFree(big);
+    }
     for (int waves = 4; waves <= 8; waves += 4) {
         for (int mode = 0; mode < 4; ++mode) {
             hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);

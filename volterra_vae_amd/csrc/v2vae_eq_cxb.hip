@@ -74,19 +74,22 @@ __global__ __launch_bounds__(NT) void k_eq_fwd_cxb(Lay l, const float* __restric
     float* tile = sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int bl = lane & 31, h = lane >> 5;
-    const int64_t b0 = l.sym_lo + (int64_t)blockIdx.x * EQ_TB;
-    eqcxb_load_tile(l, y, b0 * l.S - l.hl, tile);
     const int steps = l.eqcx_steps, LK = l.eqcx_lk;
     float* s_A = tile + ((l.ns * l.tile_len + 63) & ~63);
-    {
+    {   // the kernel table is staged once per (persistent) workgroup
         const float4* src = reinterpret_cast<const float4*>(ws + l.o_eqcxbA);
         float4* dst = reinterpret_cast<float4*>(s_A);
         for (int idx = tid; idx < steps * NBL * 32; idx += NT) dst[idx] = src[idx];
     }
-    __syncthreads();
     const float* tr = tile;
     const float* ti = tile + l.tile_len;
     const float* Al = s_A + lane;
+    const int ntile = (int)((l.sym_cnt + EQ_TB - 1) / EQ_TB);
+    for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
+    const int64_t b0 = l.sym_lo + (int64_t)t * EQ_TB;
+    __syncthreads();
+    eqcxb_load_tile(l, y, b0 * l.S - l.hl, tile);
+    __syncthreads();
 #pragma unroll 1
     for (int sub = 0; sub < 2; ++sub) {
         const int bloc = wv * 64 + sub * 32 + bl;           // symbol within the block tile
@@ -96,33 +99,52 @@ __global__ __launch_bounds__(NT) void k_eq_fwd_cxb(Lay l, const float* __restric
         for (int jb = 0; jb < NBL; ++jb)
 #pragma unroll
             for (int g = 0; g < 16; ++g) { Z[jb][0][g] = 0.f; Z[jb][1][g] = 0.f; }
-        // stream 0 lags then stream 1 lags: k = 2 s + h runs over [0, 2 LK); LK is even, so a step never straddles the streams
-#pragma unroll 2
-        for (int s = 0; s < steps; ++s) {
-            const int k = 2 * s + h;
-            const int ck = k >= LK ? 1 : 0, x = k - ck * LK;
-            const float b = (ck ? ti : tr)[base - x];
+        // stream 0 lags then stream 1 lags: k = 2 s + h runs over [0, 2 LK); LK is even, so a step never straddles the streams.
+        // One wave per SIMD and the vector unit shares its pipe with the f32 MFMAs, so the loop is kept to MFMAs and LDS reads:
+        // operands of the next step are fetched before the MFMAs of this one issue (two register sets, loop unrolled by two,
+        // no copies), addresses are a per-lane base plus wave-uniform offsets.
+        const int half = LK >> 1;                        // steps per stream
+        const float* y0 = tr + base - h;                 // lag x = 2 s + h of stream 0 is y0[-2 s]
+        const float* y1 = ti + base - h;
+        auto fetch = [&](int s, float (&av)[2 * NBL], float& bv) {
+            const int in1 = s >= half ? 1 : 0;           // wave-uniform
+            bv = (in1 ? y1 : y0)[-2 * (s - in1 * half)];
             const float* As = Al + (size_t)s * NBL * 128;
 #pragma unroll
+            for (int q = 0; q < 2 * NBL; ++q) av[q] = As[q * 64];
+        };
+        auto mfmas = [&](const float (&av)[2 * NBL], float bv) {
+#pragma unroll
             for (int jb = 0; jb < NBL; ++jb) {
-                Z[jb][0] = MFMA32(As[jb * 128], b, Z[jb][0]);
-                Z[jb][1] = MFMA32(As[jb * 128 + 64], b, Z[jb][1]);
+                Z[jb][0] = MFMA32(av[2 * jb], bv, Z[jb][0]);
+                Z[jb][1] = MFMA32(av[2 * jb + 1], bv, Z[jb][1]);
             }
+        };
+        float a0[2 * NBL], a1[2 * NBL], b0v, b1v;
+        fetch(0, a0, b0v);
+        for (int s = 0; s < steps; s += 2) {             // steps is even
+            fetch(s + 1, a1, b1v);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(a0, b0v);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(s + 2 < steps ? s + 2 : s, a0, b0v);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(a1, b1v);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        // xhat = sum_j Y_j Z_j over the second-order rows, plus row l2 (the first-order part) as it is.  Masks instead of
+        // selects keep the LDS reads unconditional (no branch per row).
         float re = 0.f, im = 0.f;
 #pragma unroll
         for (int jb = 0; jb < NBL; ++jb)
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const int j = jb * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
-                if (j < l.l2) {
-                    const float ya = tr[base - j], yb = ti[base - j];
-                    re += ya * Z[jb][0][g] - yb * Z[jb][1][g];
-                    im += ya * Z[jb][1][g] + yb * Z[jb][0][g];
-                } else if (j == l.l2) {
-                    re += Z[jb][0][g];
-                    im += Z[jb][1][g];
-                }
+                const int jc = j < l.l2 ? j : l.l2;
+                const float m2 = j < l.l2 ? 1.f : 0.f, m1 = j == l.l2 ? 1.f : 0.f;
+                const float ya = fmaf(tr[base - jc], m2, m1), yb = ti[base - jc] * m2;
+                re += ya * Z[jb][0][g] - yb * Z[jb][1][g];
+                im += ya * Z[jb][1][g] + yb * Z[jb][0][g];
             }
         re += __shfl_xor(re, 32);
         im += __shfl_xor(im, 32);
@@ -131,6 +153,7 @@ __global__ __launch_bounds__(NT) void k_eq_fwd_cxb(Lay l, const float* __restric
             xhat[b - l.sym_lo] = re;
             xhat[l.sym_cnt + (b - l.sym_lo)] = im;
         }
+    }
     }
 }
 
@@ -270,7 +293,8 @@ static int eqcxb_allow_lds(K kernel, int bytes) {
 }
 
 int launch_eq_fwd_cxb(const Lay& l, const float* y, const float* ws, float* xhat, hipStream_t st) {
-    const int nblk = (int)((l.sym_cnt + EQ_TB - 1) / EQ_TB);
+    int nblk = (int)((l.sym_cnt + EQ_TB - 1) / EQ_TB);
+    if (nblk > CX_BLOCKS) nblk = CX_BLOCKS;  // persistent: one workgroup per CU (the table takes most of its LDS)
     int rc;
 #define V2VAE_LAUNCH_EQF(NBL)                                                                                     \
     do {                                                                                                          \
