@@ -1,12 +1,8 @@
-// Complex second-order Volterra equaliser on the f32 matrix cores (forward and backward).
+// Complex second-order Volterra equaliser on the f32 matrix cores: backward for kernels of up to 31 lags (the forward of every
+// length and the backward of longer kernels live in v2vae_eq_cxb.hip).
 //
-// xhat_b = sum_j k1[j] y[bS + j - p1] + Y_b^T K Y_b,  K = k2 + k2^T complex symmetric, Y_b[x] = y[bS + p2 - x].
-// With Y = Ya + j Yb the quadratic form is one complex mat-vec Z = K Y followed by a dot product:
-//     [Zr | Zi] = [Ya | Yb] . [[Kr, Ki], [-Ki, Kr]]
-// Symbols sit on the lanes, lag rows in the accumulator registers (two 32-row tiles: Zr and Zi), so the
-// dot product Y^T Z is lane-local plus one exchange with lane ^ 32.  The first-order kernel rides along
-// as the spare row l2 of each tile (its lag window is contained in the second-order one), so the whole
-// forward is a chain of v_mfma_f32_32x32x2_f32.
+// xhat_b = sum_j k1[j] y[bS + j - p1] + Y_b^T K Y_b,  K = k2 + k2^T complex symmetric, Y_b[x] = y[bS + p2 - x],
+// Y = Ya + j Yb.
 //
 // Backward: dK accumulates R += [rho | sigma]^T [Ya | Yb] over symbols with rho = g0 Ya + g1 Yb,
 // sigma = g1 Ya - g0 Yb (g = dloss/dxhat), four 32x32 tiles per wave, two symbols per k-step; a ones
@@ -33,90 +29,6 @@ __device__ __forceinline__ void eqcx_load_tile(const Lay& l, const float* __rest
             if (loc >= 0 && loc < l.y_len) v = y[(int64_t)c * l.y_stride + loc];
         }
         tile[idx] = v;
-    }
-}
-
-// A-operand table for the forward: tab[tile(2)][step(EQCX_STEPS)][64 lanes]
-__global__ __launch_bounds__(NT) void k_prep_eqcx(Lay l, const float* __restrict__ k1, const float* __restrict__ k2,
-                                                  float* __restrict__ ws) {
-    const int l1 = l.l1, l2 = l.l2, p1 = l.pad1, p2 = l.p2, LK = l.eqcx_lk;
-    const float* k1r = k1;
-    const float* k1i = k1 + l1;
-    const float* k2r = k2;
-    const float* k2i = k2 + (size_t)l2 * l2;
-    const int n = 2 * l.eqcx_steps * 64;
-    for (int idx = blockIdx.x * NT + threadIdx.x; idx < n; idx += gridDim.x * NT) {
-        const int lane = idx & 63, s = (idx >> 6) % l.eqcx_steps, tile = idx / (64 * l.eqcx_steps);
-        const int j = lane & 31, h = lane >> 5;
-        const int k = 2 * s + h, ck = k >= LK ? 1 : 0, x = k - ck * LK;   // stacked input lag (stream ck, lag x)
-        float v = 0.f;
-        if (x < l2) {
-            if (j < l2) {
-                const float kr = k2r[x * l2 + j] + k2r[j * l2 + x], ki = k2i[x * l2 + j] + k2i[j * l2 + x];
-                // [[Kr, Ki], [-Ki, Kr]] : rows (ck, x), column tile 0 = Zr, 1 = Zi
-                v = ck == 0 ? (tile == 0 ? kr : ki) : (tile == 0 ? -ki : kr);
-            } else if (j == l2) {
-                const int jj = p1 + p2 - x;  // first-order tap that multiplies lag x
-                if (jj >= 0 && jj < l1) {
-                    const float ar = k1r[jj], ai = k1i[jj];
-                    v = ck == 0 ? (tile == 0 ? ar : ai) : (tile == 0 ? -ai : ar);
-                }
-            }
-        }
-        ws[l.o_eqcxA + idx] = v;
-    }
-}
-
-__global__ __launch_bounds__(NT) void k_eq_fwd_cx(Lay l, const float* __restrict__ y, const float* __restrict__ ws,
-                                                  float* __restrict__ xhat) {
-    extern __shared__ float sm[];
-    float* tile = sm;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int bl = lane & 31, h = lane >> 5;
-    const int64_t b0 = l.sym_lo + (int64_t)blockIdx.x * EQ_TB;
-    eqcx_load_tile(l, y, b0 * l.S - l.hl, tile);
-    const int steps = l.eqcx_steps, LK = l.eqcx_lk;
-    float* s_A = tile + l.ns * l.tile_len;  // [2][steps][64] constant A operands, staged once per block
-    for (int idx = tid; idx < 2 * steps * 64; idx += NT) s_A[idx] = ws[l.o_eqcxA + idx];
-    const float* A0 = s_A + lane;
-    const float* A1 = A0 + steps * 64;
-    __syncthreads();
-    const float* tr = tile;
-    const float* ti = tile + l.tile_len;
-#pragma unroll 1
-    for (int sub = 0; sub < 2; ++sub) {
-        const int bloc = wv * 64 + sub * 32 + bl;           // symbol within the block tile
-        const int base = bloc * l.S + l.hl + l.p2;          // tile index of lag 0
-        f32x16 Zr, Zi;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) { Zr[g] = 0.f; Zi[g] = 0.f; }
-        for (int s = 0; s < steps; ++s) {
-            const int k = 2 * s + h;
-            const int ck = k >= LK ? 1 : 0, x = k - ck * LK;
-            const float b = (ck ? ti : tr)[base - x];
-            Zr = MFMA32(A0[s * 64], b, Zr);
-            Zi = MFMA32(A1[s * 64], b, Zi);
-        }
-        float re = 0.f, im = 0.f;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const int j = (g & 3) + 8 * (g >> 2) + 4 * h;
-            if (j < l.l2) {
-                const float ya = tr[base - j], yb = ti[base - j];
-                re += ya * Zr[g] - yb * Zi[g];
-                im += ya * Zi[g] + yb * Zr[g];
-            } else if (j == l.l2) {
-                re += Zr[g];
-                im += Zi[g];
-            }
-        }
-        re += __shfl_xor(re, 32);
-        im += __shfl_xor(im, 32);
-        const int64_t b = b0 + bloc;
-        if (h == 0 && b < l.sym_lo + l.sym_cnt) {
-            xhat[b - l.sym_lo] = re;
-            xhat[l.sym_cnt + (b - l.sym_lo)] = im;
-        }
     }
 }
 
@@ -203,17 +115,6 @@ __global__ __launch_bounds__(NT) void k_chain_equaliser_cx(Lay l, const float* _
             g_k2[e] = GK(p, a, b) + GK(p, b, a);
         }
     }
-}
-
-int launch_prep_eqcx(const Lay& l, const float* k1, const float* k2, float* ws, hipStream_t st) {
-    hipLaunchKernelGGL(k_prep_eqcx, dim3(8), dim3(NT), 0, st, l, k1, k2, ws);
-    return V2VAE_OK;
-}
-
-int launch_eq_fwd_cx(const Lay& l, const float* y, const float* ws, float* xhat, hipStream_t st) {
-    const int nblk = (int)((l.sym_cnt + EQ_TB - 1) / EQ_TB);
-    hipLaunchKernelGGL(k_eq_fwd_cx, dim3(nblk), dim3(NT), l.lds_eq, st, l, y, ws, xhat);
-    return V2VAE_OK;
 }
 
 int launch_eq_bwd_cx(const Lay& l, const float* y, const float* gx, float* ws, hipStream_t st) {

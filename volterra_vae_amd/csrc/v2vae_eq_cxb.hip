@@ -1,5 +1,6 @@
-// Complex second-order Volterra equaliser on the f32 matrix cores for LONG kernels (31 < l2 <= 95 lags), forward and
-// backward: the lag rows of v2vae_eq_cx.hip cut into NBL blocks of 32.
+// Complex second-order Volterra equaliser on the f32 matrix cores with the lag rows in NBL blocks of 32: the forward for every
+// kernel length up to 95 lags (NBL = 1, 2, 3), the backward for long kernels (31 < l2 <= 95; v2vae_eq_cx.hip has the one-block
+// backward).
 //
 // xhat_b = sum_j k1[j] y[bS + j - p1] + Y_b^T K Y_b,  K = k2 + k2^T complex symmetric, Y_b[x] = y[bS + p2 - x]
 // (lib/torch_components.py:79-96 on complex samples).
@@ -15,7 +16,7 @@
 // each of the two planes per block and k-step, two symbols per k-step).  A ones column at lag index l2 of the Ya operand (zero in
 // the Yb operand) yields the first-order gradient in the same products.
 //
-// Applies when mode = complex, l2 odd in (31, 95], l1 odd <= l2 and pad1 = l1 / 2.
+// Applies when mode = complex, l2 odd <= 95, l1 odd <= l2 and pad1 = l1 / 2.
 #include <hip/hip_runtime.h>
 
 #include "v2vae_cx_common.h"
@@ -294,14 +295,18 @@ static int eqcxb_allow_lds(K kernel, int bytes) {
 
 int launch_eq_fwd_cxb(const Lay& l, const float* y, const float* ws, float* xhat, hipStream_t st) {
     int nblk = (int)((l.sym_cnt + EQ_TB - 1) / EQ_TB);
-    if (nblk > CX_BLOCKS) nblk = CX_BLOCKS;  // persistent: one workgroup per CU (the table takes most of its LDS)
+    // persistent workgroups: as many per CU as their LDS image (sample tile + kernel table) allows, at most three
+    int per_cu = 160 * 1024 / (l.lds_eqcxb_fwd + 1024);
+    per_cu = per_cu < 1 ? 1 : per_cu > 3 ? 3 : per_cu;
+    if (nblk > CX_BLOCKS * per_cu) nblk = CX_BLOCKS * per_cu;
     int rc;
 #define V2VAE_LAUNCH_EQF(NBL)                                                                                     \
     do {                                                                                                          \
         if ((rc = eqcxb_allow_lds(k_eq_fwd_cxb<NBL>, l.lds_eqcxb_fwd))) return rc;                                \
         hipLaunchKernelGGL(k_eq_fwd_cxb<NBL>, dim3(nblk), dim3(NT), l.lds_eqcxb_fwd, st, l, y, ws, xhat);          \
     } while (0)
-    if (l.eqcxb_nbl == 2) V2VAE_LAUNCH_EQF(2);
+    if (l.eqcxb_nbl == 1) V2VAE_LAUNCH_EQF(1);
+    else if (l.eqcxb_nbl == 2) V2VAE_LAUNCH_EQF(2);
     else if (l.eqcxb_nbl == 3) V2VAE_LAUNCH_EQF(3);
     else return V2VAE_ESIZE;
 #undef V2VAE_LAUNCH_EQF

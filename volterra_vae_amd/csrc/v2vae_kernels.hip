@@ -161,6 +161,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     l.use_eqcxb = (l.mode == 1 && l.l2 > 31 && l.l2 <= 95 && (l.l1 & 1) && l.l1 <= l.l2 && l.pad1 == l.l1 / 2 &&
                    getenv("V2VAE_FORCE_GENERIC") == nullptr) ? 1 : 0;
     l.eqcxb_nbl = (l.l2 + 32) / 32;        // 32-row blocks holding lags 0 .. l2 (row l2 carries the first-order kernel)
+    l.eqcxb_fwd = (l.use_eqcxb || l.use_eqcx) ? 1 : 0;  // the blocked forward kernel also serves the one-block case
     l.eqcxb_rec = 2 * (l.eqcxb_nbl * (l.eqcxb_nbl + 1) / 2) * 1024;
     l.lds_eqcxb_fwd = (int)((rup((int64_t)l.ns * l.tile_len, 64) + (int64_t)l.eqcx_steps * l.eqcxb_nbl * 128) * 4);
     {
@@ -202,10 +203,9 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     l.o_cxbc = take(l.use_cxb ? (int64_t)l.S * 4 * l.cxb_leb : 0);
     l.o_part_cxb = take(l.use_cxb ? (int64_t)l.nblk_cxb * l.S * l.cxb_rec : 0);
     l.o_tot_cxb = take(l.use_cxb ? (int64_t)l.S * l.cxb_rec : 0);
-    l.o_eqcxA = take(l.use_eqcx ? (int64_t)2 * l.eqcx_steps * 64 : 0);
     l.o_part_eqcx = take(l.use_eqcx ? (int64_t)l.nblk_eq * 4096 : 0);
     l.o_tot_eqcx = take(l.use_eqcx ? 4096 : 0);
-    l.o_eqcxbA = take(l.use_eqcxb ? (int64_t)l.eqcx_steps * l.eqcxb_nbl * 128 : 0);
+    l.o_eqcxbA = take(l.eqcxb_fwd ? (int64_t)l.eqcx_steps * l.eqcxb_nbl * 128 : 0);
     l.o_part_eqcxb = take(l.use_eqcxb ? (int64_t)l.nblk_eq * l.eqcxb_rec : 0);
     l.o_tot_eqcxb = take(l.use_eqcxb ? l.eqcxb_rec : 0);
     {
@@ -1525,8 +1525,7 @@ int v2vae_prep_tables(const v2vae_problem* p, const float* h1, const float* h2, 
     // either group may be absent (NULL): channel tables need h1 and h2, equaliser tables k1 (and k2 if l2 > 0)
     if (!ws || (!h1 && !k1) || (h1 && !h2) || (k1 && l.l2 > 0 && !k2)) return V2VAE_EINVAL;
     hipLaunchKernelGGL(k_prep_tables, dim3(16), dim3(NT), 0, (hipStream_t)stream, l, h1, h2, k1, k2, (float*)ws);
-    if (k1 && l.use_eqcx) launch_prep_eqcx(l, k1, k2, (float*)ws, (hipStream_t)stream);
-    if (k1 && l.use_eqcxb) launch_prep_eqcxb(l, k1, k2, (float*)ws, (hipStream_t)stream);
+    if (k1 && l.eqcxb_fwd) launch_prep_eqcxb(l, k1, k2, (float*)ws, (hipStream_t)stream);
     if (h1 && l.use_cxb) launch_prep_cxb(l, h1, h2, (float*)ws, (hipStream_t)stream);
     return launch_status();
 }
@@ -1536,11 +1535,7 @@ int v2vae_eq_fwd(const v2vae_problem* p, const float* y, const void* ws, float* 
     int rc = make_layout(p, &l);
     if (rc) return rc;
     if (!y || !ws || !xhat) return V2VAE_EINVAL;
-    if (l.use_eqcx) {
-        launch_eq_fwd_cx(l, y, (const float*)ws, xhat, (hipStream_t)stream);
-        return launch_status();
-    }
-    if (l.use_eqcxb) {
+    if (l.eqcxb_fwd) {
         rc = launch_eq_fwd_cxb(l, y, (const float*)ws, xhat, (hipStream_t)stream);
         return rc ? rc : launch_status();
     }
@@ -1824,6 +1819,7 @@ int v2vae_fit_persistent(const v2vae_problem* p, const v2vae_fit_args* a, void* 
     l.use_cxb = 0;
     l.use_eqcx = 0;
     l.use_eqcxb = 0;
+    l.eqcxb_fwd = 0;
     l.nblk_E = l.nblk_elbo;
     const int lds = l.lds_elbo > l.lds_eq ? l.lds_elbo : l.lds_eq;
 #define V2VAE_LAUNCH_FIT(CB, ME)                                                                                       \

@@ -60,9 +60,9 @@ struct Lay {
     int64_t o_cxbA, o_cxbH, o_cxbc, o_part_cxb, o_tot_cxb;
     // matrix-core equaliser path
     int use_eqcx, eqcx_lk, eqcx_steps;
-    int64_t o_eqcxA, o_part_eqcx, o_tot_eqcx;
+    int64_t o_part_eqcx, o_tot_eqcx;
     // blocked matrix-core equaliser path (complex, 31 < l2 <= 95): lag rows in blocks of 32
-    int use_eqcxb, eqcxb_nbl, eqcxb_rec, lds_eqcxb_fwd, lds_eqcxb_bwd;
+    int use_eqcxb, eqcxb_fwd, eqcxb_nbl, eqcxb_rec, lds_eqcxb_fwd, lds_eqcxb_bwd;
     int64_t o_eqcxbA, o_part_eqcxb, o_tot_eqcxb;
     int64_t o_sumstage;      // 3 x [SUM_CHUNKS][largest record] staging of the two-stage record sums (one per record set)
     int64_t sumstage_stride; // floats between the three staging areas
@@ -101,8 +101,6 @@ void launch_chain_channel_cxb(const Lay& l, float* ws, const double* scal, const
 void launch_sum_records(const Lay& l, const float* part, int rec, int nrec, float* stage, float* tot, hipStream_t st);
 
 // v2vae_eq_cx.hip
-int launch_prep_eqcx(const Lay& l, const float* k1, const float* k2, float* ws, hipStream_t st);
-int launch_eq_fwd_cx(const Lay& l, const float* y, const float* ws, float* xhat, hipStream_t st);
 int launch_eq_bwd_cx(const Lay& l, const float* y, const float* gx, float* ws, hipStream_t st);
 void launch_chain_equaliser_cx(const Lay& l, float* ws, float* g_k1, float* g_k2, hipStream_t st);
 
