@@ -11,6 +11,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // tap (within a block of 16) held in accumulator register q of lane half h of a 32x32 MFMA result
+typedef float f2 __attribute__((ext_vector_type(2)));
+// two neighbouring floats as a register pair (one ds_read2_b32 / global_load_dwordx2; no alignment requirement)
+__device__ __forceinline__ f2 ld2(const float* p) { return f2{p[0], p[1]}; }
+
 __device__ __forceinline__ int cx_kk(int q, int h) { return (q & 3) + 8 * (q >> 2) + 4 * h; }
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)

@@ -46,9 +46,10 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
     constexpr int TWB = CX2_TWB, MS = CX2_MS, TP = CX_TP, NU = CX2_NU, NSIG = CX2_NSIG;
     constexpr int NWP = NW / S;
     constexpr int CX2_NT = NW * 64;
-    // one staging buffer: moments as float4 (mean, variance, 3rd central moment, 4th cumulant) [2][MS], the means
-    // again as plain arrays [2][MS] (MFMA operands want unit stride), s = v_a + v_b [MS], y' [2][S][TWB]
-    constexpr int STG = 11 * MS + 2 * S * TWB;
+    // one staging buffer of per-symbol planes [MS] each (unit stride: MFMA operands, and pairs of neighbouring taps load
+    // as register pairs for packed arithmetic): mean_a, mean_b, v_a + v_b, v_a - v_b, 3rd central moments k_a, k_b,
+    // sum of the 4th cumulants g_a + g_b; then y' [2][S][TWB]
+    constexpr int STG = 7 * MS + 2 * S * TWB;
     float* s_stage = sm;                      // [STG]; the next tile travels in registers until this one is consumed
     float* s_A = s_stage + STG;           // [S][40][64]  A operands: steps 0-15 H X, 16-23 (H.H) s, 24-39 H w
     float* s_c = s_A + S * 40 * 64;           // [S][4][16]   h1r, h1i, diag Hr, diag Hi
@@ -109,6 +110,8 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
 #define C_HI(q) cst[1 * 16 + ((q) & 3) + 8 * ((q) >> 2)]
 #define C_DR(q) cst[2 * 16 + ((q) & 3) + 8 * ((q) >> 2)]
 #define C_DI(q) cst[3 * 16 + ((q) & 3) + 8 * ((q) >> 2)]
+    // the same for the tap pair (2 p, 2 p + 1): neighbouring taps, neighbouring addresses
+#define C2(row, p) ld2(cst + (row) * 16 + ((2 * (p)) & 3) + 8 * ((2 * (p)) >> 2))
     __syncthreads();
     float dd_sum[S];
 #pragma unroll
@@ -138,9 +141,9 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
     f32x16 R;
 #pragma unroll
     for (int g = 0; g < 16; ++g) R[g] = 0.f;
-    float ghr[8], ghi[8], gdr[8], gdi[8];
+    f2 ghr[4], ghi[4], gdr[4], gdi[4];  // vector gradients of the tap pairs (2 p, 2 p + 1)
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { ghr[q] = 0.f; ghi[q] = 0.f; gdr[q] = 0.f; gdi[q] = 0.f; }
+    for (int p = 0; p < 4; ++p) { ghr[p] = 0.f; ghi[p] = 0.f; gdr[p] = 0.f; gdi[p] = 0.f; }
     double Eacc = 0.0;
 
     // staging of one block tile through registers, so that the loads of tile n + 1 are in flight while tile n is
@@ -181,22 +184,23 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
         }
     };
     auto stage_store = [&](float* dst) {
-        float4* d4 = reinterpret_cast<float4*>(dst);
 #pragma unroll
         for (int u = 0; u < NSL; ++u) {
             const int ms = tid + u * CX2_NT;
             if (ms < MS) {
-                d4[ms] = prea[u];
-                d4[MS + ms] = preb[u];
-                dst[8 * MS + ms] = prea[u].x;
-                dst[9 * MS + ms] = preb[u].x;
-                dst[10 * MS + ms] = prea[u].y + preb[u].y;
+                dst[0 * MS + ms] = prea[u].x;
+                dst[1 * MS + ms] = preb[u].x;
+                dst[2 * MS + ms] = prea[u].y + preb[u].y;
+                dst[3 * MS + ms] = prea[u].y - preb[u].y;
+                dst[4 * MS + ms] = prea[u].z;
+                dst[5 * MS + ms] = preb[u].z;
+                dst[6 * MS + ms] = prea[u].w + preb[u].w;
             }
         }
 #pragma unroll
         for (int u = 0; u < NYW; ++u) {
             const int e = tid + u * CX2_NT;
-            if (e < 2 * S * TWB) dst[11 * MS + e] = prey[u];
+            if (e < 2 * S * TWB) dst[7 * MS + e] = prey[u];
         }
     };
     if (blockIdx.x < l.ntile_cx) { stage_load(blockIdx.x); stage_store(s_stage); }
@@ -206,10 +210,13 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
         const int64_t s0 = l.own_lo + (int64_t)tile * TS;
         const int64_t s1 = (s0 + TS < own_hi) ? s0 + TS : own_hi;
         const int64_t tbase = s0 - l.kmax;
-        const float4* s_m4 = reinterpret_cast<const float4*>(s_stage);   // [2][MS]
-        const float* s_mu = s_stage + 8 * MS;                             // [2][MS]
-        const float* s_S = s_mu + 2 * MS;
-        const float* s_yw = s_S + MS;
+        const float* s_mu = s_stage;                                      // [2][MS] means
+        const float* s_S = s_stage + 2 * MS;                              // v_a + v_b
+        const float* s_dv = s_stage + 3 * MS;                             // v_a - v_b
+        const float* s_ka = s_stage + 4 * MS;
+        const float* s_kb = s_stage + 5 * MS;
+        const float* s_gs = s_stage + 6 * MS;                             // g_a + g_b
+        const float* s_yw = s_stage + 7 * MS;
         const bool more = tile + (int)gridDim.x < l.ntile_cx;
         if (more) stage_load(tile + gridDim.x);
         STAMP(0);
@@ -241,35 +248,37 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
             }
 
             STAMP(1);
-            float zP[8], zQ[8], al[8], be[8], zz[8], dvv[8];
-            float a0 = 0.f, a1 = 0.f, q0 = 0.f, q1 = 0.f, sd0 = 0.f, sd1 = 0.f, vs = 0.f;
+            // per-tap algebra on tap PAIRS (2 p, 2 p + 1): their accumulator rows, moments and constants sit in neighbouring
+            // registers / addresses, so every operation below is one packed instruction for two taps
+            f2 zP[4], zQ[4], al[4], be[4], zz[4], dvv[4];
+            f2 a0v = 0.f, a1v = 0.f, q0v = 0.f, q1v = 0.f, sd0v = 0.f, sd1v = 0.f, vsv = 0.f;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int slot = tsl + i + cx_kk(q, h);
-                const float P = U[q], Q = U[q + 8], T = TT[q];
-                const float4 m4a = s_m4[slot], m4b = s_m4[MS + slot];
-                const float ma = m4a.x, va = m4a.y, ka = m4a.z, ga = m4a.w;
-                const float mb = m4b.x, vb = m4b.y, kb = m4b.z, gb = m4b.w;
-                const float hr = C_HR(q), hi = C_HI(q), dr = C_DR(q), di = C_DI(q);
-                const float zp = fmaf(2.f, P, hr), zq = fmaf(2.f, Q, hi);
-                a0 += hr * ma - hi * mb;
-                a1 += hi * ma + hr * mb;
-                q0 += ma * P - mb * Q;
-                q1 += ma * Q + mb * P;
-                const float Sv = va + vb, dv = va - vb, gs = ga + gb;
-                sd0 = fmaf(dv, dr, sd0);
-                sd1 = fmaf(dv, di, sd1);
-                const float z2 = zp * zp + zq * zq;
-                const float ca = dr * zp + di * zq, cb = dr * zq - di * zp;
-                vs += Sv * z2 + 2.f * Sv * T + 2.f * (ka * ca + kb * cb) + gs * (dr * dr + di * di);
-                al[q] = 2.f * Sv * zp + 2.f * (ka * dr - kb * di);
-                be[q] = 2.f * Sv * zq + 2.f * (ka * di + kb * dr);
-                zP[q] = zp; zQ[q] = zq;
-                zz[q] = z2 + 4.f * T;
-                dvv[q] = dv;
-                gdr[q] += mo * (2.f * (ka * zp + kb * zq) + 2.f * gs * dr);
-                gdi[q] += mo * (2.f * (ka * zq - kb * zp) + 2.f * gs * di);
+            for (int p = 0; p < 4; ++p) {
+                const int slot = tsl + i + cx_kk(2 * p, h);
+                const f2 P = f2{U[2 * p], U[2 * p + 1]}, Q = f2{U[2 * p + 8], U[2 * p + 9]}, T = f2{TT[2 * p], TT[2 * p + 1]};
+                const f2 ma = ld2(s_mu + slot), mb = ld2(s_mu + MS + slot), Sv = ld2(s_S + slot), dv = ld2(s_dv + slot);
+                const f2 ka = ld2(s_ka + slot), kb = ld2(s_kb + slot), gs = ld2(s_gs + slot);
+                const f2 hr = C2(0, p), hi = C2(1, p), dr = C2(2, p), di = C2(3, p);
+                const f2 zp = 2.f * P + hr, zq = 2.f * Q + hi;
+                a0v += hr * ma - hi * mb;
+                a1v += hi * ma + hr * mb;
+                q0v += ma * P - mb * Q;
+                q1v += ma * Q + mb * P;
+                sd0v += dv * dr;
+                sd1v += dv * di;
+                const f2 z2 = zp * zp + zq * zq;
+                const f2 ca = dr * zp + di * zq, cb = dr * zq - di * zp;
+                vsv += Sv * (z2 + 2.f * T) + 2.f * (ka * ca + kb * cb) + gs * (dr * dr + di * di);
+                al[p] = 2.f * (Sv * zp + ka * dr - kb * di);
+                be[p] = 2.f * (Sv * zq + ka * di + kb * dr);
+                zP[p] = zp; zQ[p] = zq;
+                zz[p] = z2 + 4.f * T;
+                dvv[p] = dv;
+                gdr[p] += (2.f * mo) * (ka * zp + kb * zq + gs * dr);
+                gdi[p] += (2.f * mo) * (ka * zq - kb * zp + gs * di);
             }
+            float a0 = a0v.x + a0v.y, a1 = a1v.x + a1v.y, q0 = q0v.x + q0v.y, q1 = q1v.x + q1v.y;
+            float sd0 = sd0v.x + sd0v.y, sd1 = sd1v.x + sd1v.y, vs = vsv.x + vsv.y;
             a0 += __shfl_xor(a0, 32); a1 += __shfl_xor(a1, 32);
             q0 += __shfl_xor(q0, 32); q1 += __shfl_xor(q1, 32);
             sd0 += __shfl_xor(sd0, 32); sd1 += __shfl_xor(sd1, 32);
@@ -285,10 +294,11 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
             for (int g = 0; g < 16; ++g) HW[g] = 0.f;
 #ifdef ABLATE_HW
 #pragma unroll
-            for (int s = 0; s < 16; ++s) HW[s] = (s < 8 ? al[s & 7] : be[s & 7]);
+            for (int s = 0; s < 16; ++s) HW[s] = (s < 8 ? al[(s & 7) >> 1][s & 1] : be[(s & 7) >> 1][s & 1]);
 #else
 #pragma unroll
-            for (int s = 0; s < 16; ++s) HW = MFMA32(Aop[(24 + s) * 64], s < 8 ? al[s & 7] : be[s & 7], HW);
+            for (int s = 0; s < 16; ++s)
+                HW = MFMA32(Aop[(24 + s) * 64], s < 8 ? al[(s & 7) >> 1][s & 1] : be[(s & 7) >> 1][s & 1], HW);
 #endif
 
             // ---- anti-diagonal sums of the moment gradients, two quantities per round through the wave's buffer
@@ -299,28 +309,32 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
             float* Pu = s_P + ((size_t)(r * NU + sub) * 6) * NSIG;
 #ifdef ABLATE_ANTIDIAG
 #pragma unroll
-            for (int q = 0; q < 8; ++q) asm volatile("" ::"v"(HW[q]), "v"(HW[q + 8]), "v"(zz[q]));
+            for (int q = 0; q < 8; ++q) asm volatile("" ::"v"(HW[q]), "v"(HW[q + 8]), "v"(zz[q >> 1][q & 1]));
 #else
 #pragma unroll
             for (int round = 0; round < 3; ++round) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int x = cx_kk(q, h);
-                    const float zp = zP[q], zq = zQ[q], dr = C_DR(q), di = C_DI(q);
-                    float da, db;
+                for (int p = 0; p < 4; ++p) {
+                    const int x = cx_kk(2 * p, h);
+                    const f2 zp = zP[p], zq = zQ[p], dr = C2(2, p), di = C2(3, p);
+                    f2 da, db;
                     if (round == 0) {
-                        da = 2.f * (e0 * zp + e1 * zq) + 2.f * HW[q];
-                        db = 2.f * (e1 * zp - e0 * zq) + 2.f * HW[q + 8];
+                        da = 2.f * (e0 * zp + e1 * zq + f2{HW[2 * p], HW[2 * p + 1]});
+                        db = 2.f * (e1 * zp - e0 * zq + f2{HW[2 * p + 8], HW[2 * p + 9]});
                     } else if (round == 1) {
-                        const float ed = 2.f * (e0 * dr + e1 * di);
-                        da = zz[q] + ed;
-                        db = zz[q] - ed;
+                        const f2 ed = 2.f * (e0 * dr + e1 * di);
+                        da = zz[p] + ed;
+                        db = zz[p] - ed;
                     } else {
                         da = 2.f * (dr * zp + di * zq);
                         db = 2.f * (dr * zq - di * zp);
                     }
-                    Bd0[x * 48 + i] = mv * da;
-                    Bd1[x * 48 + i] = mv * db;
+                    da *= mv;
+                    db *= mv;
+                    Bd0[x * 48 + i] = da.x;
+                    Bd0[(x + 1) * 48 + i] = da.y;
+                    Bd1[x * 48 + i] = db.x;
+                    Bd1[(x + 1) * 48 + i] = db.y;
                 }
                 __builtin_amdgcn_wave_barrier();
                 if (lane < 48) {
@@ -340,17 +354,20 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
             STAMP(4);
             // ---- rho / sigma (transposed through LDS), vector gradients
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int x = cx_kk(q, h);
+            for (int p = 0; p < 4; ++p) {
+                const int x = cx_kk(2 * p, h);
                 const int slot = tsl + i + x;
-                const float ma = s_mu[slot], mb = s_mu[MS + slot];
-                const float gr = 2.f * (e0 * ma + e1 * mb), gi = 2.f * (e1 * ma - e0 * mb);
-                ghr[q] += mo * (gr + al[q]);
-                ghi[q] += mo * (gi + be[q]);
-                gdr[q] += mo * 2.f * e0 * dvv[q];
-                gdi[q] += mo * 2.f * e1 * dvv[q];
-                Tb[i * TP + x] = mo * (gr + 2.f * al[q]);
-                Tb[i * TP + 16 + x] = mo * (gi + 2.f * be[q]);
+                const f2 ma = ld2(s_mu + slot), mb = ld2(s_mu + MS + slot);
+                const f2 gr = 2.f * (e0 * ma + e1 * mb), gi = 2.f * (e1 * ma - e0 * mb);
+                ghr[p] += mo * (gr + al[p]);
+                ghi[p] += mo * (gi + be[p]);
+                gdr[p] += (mo * 2.f * e0) * dvv[p];
+                gdi[p] += (mo * 2.f * e1) * dvv[p];
+                const f2 t0 = mo * (gr + 2.f * al[p]), t1 = mo * (gi + 2.f * be[p]);
+                Tb[i * TP + x] = t0.x;
+                Tb[i * TP + x + 1] = t0.y;
+                Tb[i * TP + 16 + x] = t1.x;
+                Tb[i * TP + 16 + x + 1] = t1.y;
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -418,7 +435,7 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
     float vsum[8][4];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        float v0 = ghr[q], v1 = ghi[q], v2 = gdr[q], v3 = gdi[q];
+        float v0 = ghr[q >> 1][q & 1], v1 = ghi[q >> 1][q & 1], v2 = gdr[q >> 1][q & 1], v3 = gdi[q >> 1][q & 1];
 #pragma unroll
         for (int off = 1; off < 32; off <<= 1) {
             v0 += __shfl_xor(v0, off); v1 += __shfl_xor(v1, off);
