@@ -384,7 +384,7 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
             posterior_temperatures<CB>(p_sc, C, nv, inv_den);
             float prk[MAX_C];
 #pragma unroll
-            for (int k = 0; k < CB; ++k) prk[k] = k < C ? prior[k] : 1.f;
+            for (int k = 0; k < CB; ++k) prk[k] = k < C ? 1.f / prior[k] : 1.f;  // inverse priors
             for (int b = tid; b < B; b += RS_NT) {
                 const float x = s_x[b];
                 Posterior p;
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
                 float klb = 0.f;
 #pragma unroll
                 for (int k = 0; k < CB; ++k)
-                    if (k < C) klb += p.q[k] * logf(p.q[k] / prk[k] + 1e-12f);
+                    if (k < C) klb += p.q[k] * __logf(fmaf(p.q[k], prk[k], 1e-12f));
                 if (b >= l.kl_lo && b < l.kl_hi) kl += (double)klb;
                 if (a.y_eq) a.y_eq[(int64_t)model * a.n_batches * B + (int64_t)n * B + b] = x;
             }
@@ -624,13 +624,14 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
             for (int k = 0; k < CB; ++k) gs[k] = 0.f;
             double inv_den[MAX_C];
             posterior_temperatures<CB>(p_sc, C, nv, inv_den);
-            float idn[MAX_C], idsc[MAX_C], lvk[MAX_C], prk[MAX_C];
+            float idn[MAX_C], idsc[MAX_C], lvk[MAX_C], prk[MAX_C], epr[MAX_C];
 #pragma unroll
             for (int k = 0; k < CB; ++k) {
                 idn[k] = (float)inv_den[k];
                 idsc[k] = k < C ? (float)(inv_den[k] / (double)p_sc[k]) : 0.f;
                 lvk[k] = k < C ? levels[k] : 0.f;
-                prk[k] = k < C ? prior[k] : 1.f;
+                prk[k] = k < C ? 1.f / prior[k] : 1.f;    // inverse prior
+                epr[k] = k < C ? 1e-12f * prior[k] : 1.f;
             }
             for (int b = tid; b < B; b += RS_NT) {
                 const float x = s_x[b];
@@ -656,7 +657,7 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
                     const float d = lvk[k] - pmu, d2 = d * d;
                     float vk = gmu * d + gv * d2 + gk * (d2 * d - 3.f * pvar * d) + gg * (d2 * d2 - 4.f * pkap * d - 6.f * pvar * d2);
                     vk *= lam;
-                    if (in_kl) vk += logf(q[k] / prk[k] + 1e-12f) + q[k] / (q[k] + 1e-12f * prk[k]);
+                    if (in_kl) vk += __logf(fmaf(q[k], prk[k], 1e-12f)) + q[k] * __builtin_amdgcn_rcpf(q[k] + epr[k]);
                     v[k] = vk;
                 }
                 float gxa = 0.f;

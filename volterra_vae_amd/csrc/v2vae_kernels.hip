@@ -462,6 +462,11 @@ __device__ __forceinline__ void d_demap_moments(const GridCtx gc, Lay l, const f
     double inv_den[2][MAX_C];
     posterior_temperatures<CB>(scaling, l.C, nv, inv_den[0]);
     posterior_temperatures<CB>(scaling + (l.ns - 1) * l.C, l.C, nv, inv_den[1]);
+    float inv_pr[2][MAX_C];  // 1 / prior, once per thread instead of a division per symbol and level
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int k = 0; k < CB; ++k) inv_pr[c][k] = (c < l.ns && k < l.C) ? 1.f / prior[c * l.C + k] : 0.f;
     for (int64_t i = (int64_t)gc.bid * NT + threadIdx.x; i < l.sym_cnt; i += (int64_t)gc.nb * NT) {
         const int64_t b = l.sym_lo + i;
         const bool in_kl = b >= l.kl_lo && b < l.kl_hi && b >= l.own_lo && b < l.own_lo + l.own_cnt;
@@ -477,7 +482,7 @@ __device__ __forceinline__ void d_demap_moments(const GridCtx gc, Lay l, const f
             for (int k = 0; k < CB; ++k)
                 if (k < l.C) {
                     if (q_out) q_out[((int64_t)c * l.C + k) * l.sym_cnt + i] = p.q[k];
-                    klb += p.q[k] * logf(p.q[k] / prior[c * l.C + k] + 1e-12f);
+                    klb += p.q[k] * __logf(fmaf(p.q[k], inv_pr[c][k], 1e-12f));  // argument >= 1e-12: the hardware log is exact enough
                 }
             if (in_kl) kl += (double)klb;
         }
@@ -534,6 +539,19 @@ __device__ __forceinline__ void d_sym_bwd(const GridCtx gc, Lay l, const float* 
     double inv_den[2][MAX_C];
     posterior_temperatures<CB>(scaling, l.C, nv, inv_den[0]);
     posterior_temperatures<CB>(scaling + (l.ns - 1) * l.C, l.C, nv, inv_den[1]);
+    // per-level constants, once per thread: 1 / prior, 1e-12 * prior, 1 / (nv sc) and 1 / (nv sc^2) in float
+    float inv_pr[2][MAX_C], eps_pr[2][MAX_C], idn_f[2][MAX_C], idn_sc[2][MAX_C];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int k = 0; k < CB; ++k) {
+            const bool in = c < l.ns && k < l.C;
+            const float pr = in ? prior[c * l.C + k] : 1.f;
+            inv_pr[c][k] = 1.f / pr;
+            eps_pr[c][k] = 1e-12f * pr;
+            idn_f[c][k] = (float)inv_den[c][k];
+            idn_sc[c][k] = in ? idn_f[c][k] / scaling[c * l.C + k] : 0.f;
+        }
     for (int64_t i = (int64_t)gc.bid * NT + threadIdx.x; i < l.sym_cnt; i += (int64_t)gc.nb * NT) {
         const int64_t b = l.sym_lo + i;
         const bool own = b >= l.own_lo && b < l.own_lo + l.own_cnt;
@@ -545,7 +563,6 @@ __device__ __forceinline__ void d_sym_bwd(const GridCtx gc, Lay l, const float* 
                 if (own) {
                     const float x = xhat[(int64_t)c * l.sym_cnt + i];
                     const float* lv = levels + c * l.C;
-                    const float* sc = scaling + c * l.C;
                     Posterior p;
                     posterior<CB>(x, lv, inv_den[c], l.C, p);
                     const float* g = gmom + (int64_t)c * 4 * l.sym_cnt + i;
@@ -561,10 +578,9 @@ __device__ __forceinline__ void d_sym_bwd(const GridCtx gc, Lay l, const float* 
                             float vk = gmu * d + gv * d2 + gk * (d2 * d - 3.f * p.var * d) +
                                        gg * (d2 * d2 - 4.f * p.kap * d - 6.f * p.var * d2);
                             vk *= lam;
-                            if (in_kl) {
-                                const float pr = prior[c * l.C + k];
-                                vk += logf(p.q[k] / pr + 1e-12f) + p.q[k] / (p.q[k] + 1e-12f * pr);
-                            }
+                            if (in_kl)
+                                vk += __logf(fmaf(p.q[k], inv_pr[c][k], 1e-12f)) +
+                                      p.q[k] * __builtin_amdgcn_rcpf(p.q[k] + eps_pr[c][k]);
                             v[k] = vk * gsc;
                         }
                     float gxa = 0.f;
@@ -577,9 +593,8 @@ __device__ __forceinline__ void d_sym_bwd(const GridCtx gc, Lay l, const float* 
                                 if (j < l.C && j != k) sk = fmaf(p.q[j], v[k] - v[j], sk);
                             const float dz = p.q[k] * sk;
                             const float df = x - lv[k];
-                            const float idn = (float)inv_den[c][k];
-                            gxa = fmaf(dz, -2.f * df * idn, gxa);
-                            gs[c][k] = fmaf(dz * df, df * (idn / sc[k]), gs[c][k]);
+                            gxa = fmaf(dz, -2.f * df * idn_f[c][k], gxa);
+                            gs[c][k] = fmaf(dz * df, df * idn_sc[c][k], gs[c][k]);
                         }
                     gx = gxa;
                 }

@@ -41,10 +41,12 @@ __device__ __forceinline__ void posterior(float x, const float* __restrict__ lv,
 #pragma unroll
     for (int i = 0; i < CB; ++i)
         if (i < C) {
-            p.q[i] = expf((float)(zd[i] - mx));
+            // the argument is <= 0 and already a difference: the hardware exponential (1 ulp, flushes below 1e-38) loses
+            // nothing against the library one here and costs a fifth of its instructions
+            p.q[i] = __expf((float)(zd[i] - mx));
             sum += p.q[i];
         }
-    const float inv = 1.f / sum;
+    const float inv = __builtin_amdgcn_rcpf(sum);  // sum is in [1, C]
     float mu = 0.f;
 #pragma unroll
     for (int i = 0; i < CB; ++i)
