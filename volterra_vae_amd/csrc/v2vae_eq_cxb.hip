@@ -8,7 +8,9 @@
 // Forward: [Zr | Zi] = [Ya | Yb] . [[Kr, Ki], [-Ki, Kr]] with symbols on the lanes and lag rows in the accumulator
 // registers: 2 * NBL tiles of 32 rows per 32 symbols, all fed by the same B operand per k-step, so every k-step is 2 * NBL
 // independent v_mfma_f32_32x32x2_f32.  The constant A operands (the kernel table, up to 147 KB) stay in LDS for the whole
-// workgroup; row l2 of the table carries the first-order kernel.  xhat = Y^T Z is lane-local plus one exchange with lane ^ 32.
+// workgroup.  The first-order kernel, mapped to lag indices, is the INITIAL value of the accumulators (xhat = sum_j Y_j (Z_j +
+// k1'_j)), so no row needs special treatment and xhat = Y^T Z is a packed complex dot product over row pairs, lane-local plus
+// one exchange with lane ^ 32.
 //
 // Backward: with rho = g0 Ya + g1 Yb, sigma = g1 Ya - g0 Yb (g = dloss/dxhat) the gradient of the effective kernel is
 //     dKr = sum_b rho^T Ya + sigma^T Yb,   dKi = sum_b sigma^T Ya - rho^T Yb,
@@ -38,7 +40,8 @@ __device__ __forceinline__ void eqcxb_load_tile(const Lay& l, const float* __res
     }
 }
 
-// A-operand table of the forward: tab[step][row block][plane (Zr, Zi)][64 lanes]
+// A-operand table of the forward: tab[step][row block][plane (Zr, Zi)][64 lanes], followed by the first-order kernel on lag
+// indices: k1w[plane][NBL * 32] with k1w[x] = k1[pad1 + p2 - x]
 __global__ __launch_bounds__(NT) void k_prep_eqcxb(Lay l, const float* __restrict__ k1, const float* __restrict__ k2,
                                                    float* __restrict__ ws) {
     const int l1 = l.l1, l2 = l.l2, p1 = l.pad1, p2 = l.p2, LK = l.eqcx_lk, NBL = l.eqcxb_nbl;
@@ -56,15 +59,14 @@ __global__ __launch_bounds__(NT) void k_prep_eqcxb(Lay l, const float* __restric
             if (j < l2) {
                 const float kr = k2r[x * l2 + j] + k2r[j * l2 + x], ki = k2i[x * l2 + j] + k2i[j * l2 + x];
                 v = ck == 0 ? (plane == 0 ? kr : ki) : (plane == 0 ? -ki : kr);  // [[Kr, Ki], [-Ki, Kr]]
-            } else if (j == l2) {
-                const int jj = p1 + p2 - x;  // first-order tap that multiplies lag x
-                if (jj >= 0 && jj < l1) {
-                    const float ar = k1r[jj], ai = k1i[jj];
-                    v = ck == 0 ? (plane == 0 ? ar : ai) : (plane == 0 ? -ai : ar);
-                }
             }
         }
         ws[l.o_eqcxbA + idx] = v;
+    }
+    for (int idx = blockIdx.x * NT + threadIdx.x; idx < 2 * NBL * 32; idx += gridDim.x * NT) {
+        const int plane = idx / (NBL * 32), x = idx - plane * NBL * 32;
+        const int jj = p1 + p2 - x;  // first-order tap that multiplies lag x
+        ws[l.o_eqcxbA + n + idx] = (x < l2 && jj >= 0 && jj < l1) ? (plane == 0 ? k1r[jj] : k1i[jj]) : 0.f;
     }
 }
 
@@ -80,8 +82,9 @@ __global__ __launch_bounds__(NT) void k_eq_fwd_cxb(Lay l, const float* __restric
     {   // the kernel table is staged once per (persistent) workgroup
         const float4* src = reinterpret_cast<const float4*>(ws + l.o_eqcxbA);
         float4* dst = reinterpret_cast<float4*>(s_A);
-        for (int idx = tid; idx < steps * NBL * 32; idx += NT) dst[idx] = src[idx];
+        for (int idx = tid; idx < steps * NBL * 32 + NBL * 16; idx += NT) dst[idx] = src[idx];
     }
+    const float4* s_k1w = reinterpret_cast<const float4*>(s_A + (size_t)steps * NBL * 128);  // [2][NBL * 8] float4
     const float* tr = tile;
     const float* ti = tile + l.tile_len;
     const float* Al = s_A + lane;
@@ -95,11 +98,18 @@ __global__ __launch_bounds__(NT) void k_eq_fwd_cxb(Lay l, const float* __restric
     for (int sub = 0; sub < 2; ++sub) {
         const int bloc = wv * 64 + sub * 32 + bl;           // symbol within the block tile
         const int base = bloc * l.S + l.hl + l.p2;          // tile index of lag 0
+        // accumulators start from the first-order kernel of their rows (rows (g & 3) + 8 (g >> 2) + 4 h: four float4 per tile)
         f32x16 Z[NBL][2];
 #pragma unroll
         for (int jb = 0; jb < NBL; ++jb)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) { Z[jb][0][g] = 0.f; Z[jb][1][g] = 0.f; }
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const float4 v = s_k1w[pl * NBL * 8 + jb * 8 + 2 * g4 + h];
+                    Z[jb][pl][4 * g4 + 0] = v.x; Z[jb][pl][4 * g4 + 1] = v.y;
+                    Z[jb][pl][4 * g4 + 2] = v.z; Z[jb][pl][4 * g4 + 3] = v.w;
+                }
         // stream 0 lags then stream 1 lags: k = 2 s + h runs over [0, 2 LK); LK is even, so a step never straddles the streams.
         // One wave per SIMD and the vector unit shares its pipe with the f32 MFMAs, so the loop is kept to MFMAs and LDS reads:
         // operands of the next step are fetched before the MFMAs of this one issue (two register sets, loop unrolled by two,
@@ -133,20 +143,22 @@ __global__ __launch_bounds__(NT) void k_eq_fwd_cxb(Lay l, const float* __restric
             mfmas(a1, b1v);
             __builtin_amdgcn_sched_barrier(0);
         }
-        // xhat = sum_j Y_j Z_j over the second-order rows, plus row l2 (the first-order part) as it is.  Masks instead of
-        // selects keep the LDS reads unconditional (no branch per row).
-        float re = 0.f, im = 0.f;
+        // xhat = sum_j Y_j Z_j as a packed complex dot product over row pairs (j, j + 1), j even.  Rows from l2 on hold
+        // zeros in Z; their samples only have to be finite, so the pair start is clamped to l2 - 1 (lag l2 is inside the tile).
+        f2 re2 = 0.f, im2 = 0.f;
 #pragma unroll
         for (int jb = 0; jb < NBL; ++jb)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
+            for (int g = 0; g < 16; g += 2) {
                 const int j = jb * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
-                const int jc = j < l.l2 ? j : l.l2;
-                const float m2 = j < l.l2 ? 1.f : 0.f, m1 = j == l.l2 ? 1.f : 0.f;
-                const float ya = fmaf(tr[base - jc], m2, m1), yb = ti[base - jc] * m2;
-                re += ya * Z[jb][0][g] - yb * Z[jb][1][g];
-                im += ya * Z[jb][1][g] + yb * Z[jb][0][g];
+                const int a = j < l.l2 - 1 ? j : l.l2 - 1;
+                const f2 yar = ld2(tr + base - a - 1), ybr = ld2(ti + base - a - 1);   // (y[a + 1], y[a])
+                const f2 ya = __builtin_shufflevector(yar, yar, 1, 0), yb = __builtin_shufflevector(ybr, ybr, 1, 0);
+                const f2 zr = f2{Z[jb][0][g], Z[jb][0][g + 1]}, zi = f2{Z[jb][1][g], Z[jb][1][g + 1]};
+                re2 += ya * zr - yb * zi;
+                im2 += ya * zi + yb * zr;
             }
+        float re = re2.x + re2.y, im = im2.x + im2.y;
         re += __shfl_xor(re, 32);
         im += __shfl_xor(im, 32);
         const int64_t b = b0 + bloc;

@@ -163,7 +163,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     l.eqcxb_nbl = (l.l2 + 32) / 32;        // 32-row blocks holding lags 0 .. l2 (row l2 carries the first-order kernel)
     l.eqcxb_fwd = (l.use_eqcxb || l.use_eqcx) ? 1 : 0;  // the blocked forward kernel also serves the one-block case
     l.eqcxb_rec = 2 * (l.eqcxb_nbl * (l.eqcxb_nbl + 1) / 2) * 1024;
-    l.lds_eqcxb_fwd = (int)((rup((int64_t)l.ns * l.tile_len, 64) + (int64_t)l.eqcx_steps * l.eqcxb_nbl * 128) * 4);
+    l.lds_eqcxb_fwd = (int)((rup((int64_t)l.ns * l.tile_len, 64) + (int64_t)l.eqcx_steps * l.eqcxb_nbl * 128 + l.eqcxb_nbl * 64) * 4);
     {
         const int64_t a = (int64_t)l.ns * l.tile_len + 2 * EQ_TB, b = l.eqcxb_rec;
         l.lds_eqcxb_bwd = (int)((a > b ? a : b) * 4);
@@ -205,7 +205,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     l.o_tot_cxb = take(l.use_cxb ? (int64_t)l.S * l.cxb_rec : 0);
     l.o_part_eqcx = take(l.use_eqcx ? (int64_t)l.nblk_eq * 4096 : 0);
     l.o_tot_eqcx = take(l.use_eqcx ? 4096 : 0);
-    l.o_eqcxbA = take(l.eqcxb_fwd ? (int64_t)l.eqcx_steps * l.eqcxb_nbl * 128 : 0);
+    l.o_eqcxbA = take(l.eqcxb_fwd ? (int64_t)l.eqcx_steps * l.eqcxb_nbl * 128 + l.eqcxb_nbl * 64 : 0);
     l.o_part_eqcxb = take(l.use_eqcxb ? (int64_t)l.nblk_eq * l.eqcxb_rec : 0);
     l.o_tot_eqcxb = take(l.use_eqcxb ? l.eqcxb_rec : 0);
     {
