@@ -307,9 +307,9 @@ static int eqcxb_allow_lds(K kernel, int bytes) {
 
 int launch_eq_fwd_cxb(const Lay& l, const float* y, const float* ws, float* xhat, hipStream_t st) {
     int nblk = (int)((l.sym_cnt + EQ_TB - 1) / EQ_TB);
-    // persistent workgroups: as many per CU as their LDS image (sample tile + kernel table) allows, at most three
+    // persistent workgroups: as many per CU as their LDS image (sample tile + kernel table) allows, at most four
     int per_cu = 160 * 1024 / (l.lds_eqcxb_fwd + 1024);
-    per_cu = per_cu < 1 ? 1 : per_cu > 3 ? 3 : per_cu;
+    per_cu = per_cu < 1 ? 1 : per_cu > 4 ? 4 : per_cu;
     if (nblk > CX_BLOCKS * per_cu) nblk = CX_BLOCKS * per_cu;
     int rc;
 #define V2VAE_LAUNCH_EQF(NBL)                                                                                     \
