@@ -10,8 +10,8 @@ import volterra_vae_amd.ops as ops
 ops.lib = lib
 from volterra_vae_amd.ops import Plan
 from volterra_vae_amd.synth import nonlinear_isi_range, qam_constellation
-Lc, S, l1, l2, M = 25, 2, 25, 25, 4
-B = 1 << 22
+Lc, S, l1, l2, M = int(os.environ.get("LC", "25")), 2, 25, 25, 4
+B = 1 << int(os.environ.get("LOG2B", "22"))
 plan = Plan(ns=2, sps=S, l1=l1, pad1=l1 // 2, l2=l2, L=Lc, C_levels=M, n_glob=B * S, device="cuda")
 rx, _ = nonlinear_isi_range(1, qam_constellation(16), S, 16.0, 0, B, B)
 y = torch.from_numpy(np.stack((rx.real, rx.imag))).float().cuda().contiguous()

@@ -17,6 +17,42 @@ __device__ __forceinline__ f2 ld2(const float* p) { return f2{p[0], p[1]}; }
 
 __device__ __forceinline__ int cx_kk(int q, int h) { return (q & 3) + 8 * (q >> 2) + 4 * h; }
 
+// Sum along the anti-diagonals of a 32-window x 16-tap tile held "windows on lanes, taps in registers" in the MFMA accumulator
+// layout: lane = window + 32 h, register q holds tap (q & 3) + 8 (q >> 2) + 4 h.  Returns, on lane m (0 <= m < 47), the sum of
+// v[window][tap] over window + tap = m; lanes from 47 on return 0.  No LDS: each half of the wave is moved to lanes 0..31 of its
+// own register set (v_permlane32_swap against zero), reduced by a Horner scheme of one-lane shifts fused into the additions
+// (v_add_f32 ... wave_shr:1), and the two halves are combined with the four-lane offset between their taps.
+__device__ __forceinline__ float cx_shr1(float s) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x138 /* wave_shr:1 */, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float cx_horner8(const float (&t)[8]) {  // lane m: sum_q t[q][m - ((q & 3) + 8 (q >> 2))]
+    float s = t[7];
+    s = cx_shr1(s) + t[6];
+    s = cx_shr1(s) + t[5];
+    s = cx_shr1(s) + t[4];
+    s = cx_shr1(cx_shr1(cx_shr1(cx_shr1(s))));
+    s = cx_shr1(s) + t[3];
+    s = cx_shr1(s) + t[2];
+    s = cx_shr1(s) + t[1];
+    s = cx_shr1(s) + t[0];
+    return s;
+}
+__device__ __forceinline__ float cx_antidiag(const float (&v)[8]) {
+    float lo[8], hi[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        // after the swap: lo = (v of lanes 0..31 | 0), hi = (v of lanes 32..63 moved to lanes 0..31 | 0).  Written as inline
+        // assembly because the compiler's builtin returns its first result twice when the second operand is a zero; the
+        // s_nop cover the VALU-write -> permlane-swap hazards the compiler cannot see inside the statement.
+        float x = v[q], z = 0.f;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(z));
+        lo[q] = x;
+        hi[q] = z;
+    }
+    const float a = cx_horner8(lo), b = cx_horner8(hi);   // b belongs to taps + 4
+    return a + cx_shr1(cx_shr1(cx_shr1(cx_shr1(b))));
+}
+
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 

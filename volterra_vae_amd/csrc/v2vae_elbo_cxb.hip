@@ -87,12 +87,10 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
     constexpr int LEB = 16 * NB, MS = TWB + LEB + 16, NSIG = 32 + LEB, NWP = NW / S;
     constexpr int REC = 2 * LEB * LEB + 4 * LEB;
     constexpr int STG = 11 * MS + 2 * S * TWB;
-    constexpr int ADB = 16 + 16 * 48;
     float* s_stage = sm;                       // moments float4 [2][MS] | means [2][MS] | s [MS] | y' [2][S][TWB]
     float* s_c = s_stage + STG;                // [S][4][LEB]  h1r, h1i, diag Hr, diag Hi
     float* s_T = s_c + S * 4 * LEB;            // [NW][32 * TP]  transposing buffer of rho / sigma
-    float* s_B = s_T + NW * 32 * TP;           // [NW][2][ADB]   anti-diagonal buffers (zero padded)
-    float* s_P = s_B + NW * 2 * ADB;           // [S][NU][6][NSIG] anti-diagonal partial sums
+    float* s_P = s_T + NW * 32 * TP;           // [S][NU][6][NSIG] anti-diagonal partial sums
     float* s_rec = s_P + S * NU * 6 * NSIG;    // [S][REC]
     __shared__ double dred[NW];
 
@@ -102,15 +100,12 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
     // base per wave instead of one 64-bit address per lane and load)
     const int r = __builtin_amdgcn_readfirstlane(wv / NWP), wsub = __builtin_amdgcn_readfirstlane(wv % NWP);
     float* Tb = s_T + wv * 32 * TP;
-    float* Bd0 = s_B + wv * 2 * ADB + 16;
-    float* Bd1 = Bd0 + ADB;
     const float* __restrict__ mom = ws + l.o_mom;
     float* __restrict__ gmom = ws + l.o_gmom;
     const int64_t own_hi = l.own_lo + l.own_cnt, sym_hi = l.sym_lo + l.sym_cnt;
     const int TS = TWB - l.kmax;
 
     for (int idx = tid; idx < S * 4 * LEB; idx += CXB_NT) s_c[idx] = ws[l.o_cxbc + idx];
-    for (int idx = tid; idx < NW * 2 * ADB; idx += CXB_NT) s_B[idx] = 0.f;
     for (int idx = tid; idx < S * REC; idx += CXB_NT) s_rec[idx] = 0.f;
     const float* __restrict__ Abase0 = ws + l.o_cxbA + (size_t)r * NB * NB * 40 * 64;
     const unsigned ulane = lane;
@@ -139,6 +134,20 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
         for (int q = 0; q < 8; ++q) { ghr[a][q] = 0.f; ghi[a][q] = 0.f; gdr[a][q] = 0.f; gdi[a][q] = 0.f; }
     }
     double Eacc = 0.0;
+#ifdef V2VAE_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+#define BSTAMP(k)                                                       \
+    do {                                                                \
+        __builtin_amdgcn_sched_barrier(0);                              \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                             \
+        st_acc[k] += now_ - st_last;                                    \
+        st_last = now_;                                                 \
+        __builtin_amdgcn_sched_barrier(0);                              \
+    } while (0)
+#else
+#define BSTAMP(k)
+#endif
 
     // staging of one block tile through registers: the loads of tile n + 1 are in flight while tile n is computed
     constexpr int NSL = (MS + CXB_NT - 1) / CXB_NT;
@@ -209,6 +218,7 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
         const bool more = tile + (int)gridDim.x < l.ntile_cxb;
         if (more) stage_load(tile + gridDim.x);
 
+        BSTAMP(0);
         for (int sub = wsub; sub < NU; sub += NWP) {
             const int tsl = sub * 32;
             const int64_t t = tbase + tsl + i, n = t * S + r;
@@ -254,6 +264,7 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
 #pragma unroll
                     for (int s = 0; s < 24; ++s) cur[s] = nxt[s];
                 }
+                BSTAMP(1);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int x = 16 * xb + cx_kk(q, h);
@@ -282,6 +293,7 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                     gdr[xb][q] += mo * (2.f * (ka * zp + kb * zq) + 2.f * gs * dr);
                     gdi[xb][q] += mo * (2.f * (ka * zq - kb * zp) + 2.f * gs * di);
                 }
+                BSTAMP(2);
             }
             a0 += __shfl_xor(a0, 32); a1 += __shfl_xor(a1, 32);
             q0 += __shfl_xor(q0, 32); q1 += __shfl_xor(q1, 32);
@@ -315,42 +327,37 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
 #pragma unroll
                     for (int s = 0; s < 16; ++s) curh[s] = nxth[s];
                 }
-                // anti-diagonal sums (symbol = window + tap), one pair of quantities per round through the wave's
-                // zero-padded buffers; LDS instructions of one wave execute in program order
+                BSTAMP(3);
+                // anti-diagonal sums (symbol = window + tap) of the moment gradients, one pair of quantities per round, by lane
+                // shifts inside the wave (no LDS round trip); the partial of this tap block is added to the slab's record
 #pragma unroll
                 for (int round = 0; round < 3; ++round) {
+                    float da[8], db[8];
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
-                        const int xl = cx_kk(q, h), x = 16 * xb + xl;
+                        const int x = 16 * xb + cx_kk(q, h);
                         const float zp = zP[xb][q], zq = zQ[xb][q], dr = cst[2 * LEB + x], di = cst[3 * LEB + x];
-                        float da, db;
                         if (round == 0) {
-                            da = 2.f * (e0 * zp + e1 * zq) + 2.f * HW[q];
-                            db = 2.f * (e1 * zp - e0 * zq) + 2.f * HW[q + 8];
+                            da[q] = 2.f * (e0 * zp + e1 * zq) + 2.f * HW[q];
+                            db[q] = 2.f * (e1 * zp - e0 * zq) + 2.f * HW[q + 8];
                         } else if (round == 1) {
                             const float ed = 2.f * (e0 * dr + e1 * di);
-                            da = zz[xb][q] + ed;
-                            db = zz[xb][q] - ed;
+                            da[q] = zz[xb][q] + ed;
+                            db[q] = zz[xb][q] - ed;
                         } else {
-                            da = 2.f * (dr * zp + di * zq);
-                            db = 2.f * (dr * zq - di * zp);
+                            da[q] = 2.f * (dr * zp + di * zq);
+                            db[q] = 2.f * (dr * zq - di * zp);
                         }
-                        Bd0[xl * 48 + i] = mv * da;
-                        Bd1[xl * 48 + i] = mv * db;
+                        da[q] *= mv;
+                        db[q] *= mv;
                     }
-                    __builtin_amdgcn_wave_barrier();
+                    const float sa = cx_antidiag(da), sb = cx_antidiag(db);
                     if (lane < 48) {
-                        float sa = 0.f, sb = 0.f;
-#pragma unroll
-                        for (int x = 0; x < 16; ++x) {   // row x, window lane - x
-                            sa += Bd0[x * 47 + lane];
-                            sb += Bd1[x * 47 + lane];
-                        }
                         Pu[(2 * round + 0) * NSIG + 16 * xb + lane] += sa;
                         Pu[(2 * round + 1) * NSIG + 16 * xb + lane] += sb;
                     }
-                    __builtin_amdgcn_wave_barrier();
                 }
+                BSTAMP(4);
                 // rho / sigma of this block (transposed through LDS), vector gradients
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -388,9 +395,11 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
+                BSTAMP(5);
             }
         }
         __syncthreads();
+        BSTAMP(6);
         if (more) stage_store(s_stage);
         // ---- gather: symbol slot ms = kmax + ml collects the partials of every slab whose 32 + Le - 1 slots cover it
         for (int idx = tid; idx < 2 * TS; idx += CXB_NT) {
@@ -423,7 +432,14 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
             }
         }
         __syncthreads();
+        BSTAMP(7);
     }
+#ifdef V2VAE_STAMPS
+    if (lane == 0) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(ws + l.o_sumstage);  // free until the record sums run
+        for (int k = 0; k < 8; ++k) dbg[((size_t)blockIdx.x * NW + wv) * 8 + k] = st_acc[k];
+    }
+#endif
 
     // ---- one record per (block, phase): the waves of a phase add their tiles in a fixed order
     float* img = s_rec + (size_t)r * REC;

@@ -143,7 +143,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
             l.ntile_cxb = l.use_cxb ? (int)((l.own_cnt + tsb - 1) / tsb) : 0;
             l.nblk_cxb = l.ntile_cxb < CX_BLOCKS ? l.ntile_cxb : CX_BLOCKS;
             const int ms = CXB_TWB + l.cxb_leb + 16, nsig = 32 + l.cxb_leb;
-            l.lds_cxb = ((11 * ms + 2 * l.S * CXB_TWB) + l.S * 4 * l.cxb_leb + 4 * 32 * CX_TP + 4 * 2 * (16 + 16 * 48) +
+            l.lds_cxb = ((11 * ms + 2 * l.S * CXB_TWB) + l.S * 4 * l.cxb_leb + 4 * 32 * CX_TP +
                          l.S * (CXB_TWB / 32) * 6 * nsig + l.S * l.cxb_rec) * 4;
         }
         l.nblk_E = l.use_cx ? l.nblk_cx : (l.use_cxb ? l.nblk_cxb : l.nblk_elbo);
