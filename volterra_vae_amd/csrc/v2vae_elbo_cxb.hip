@@ -229,17 +229,22 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
             for (int e = lane; e < 6 * NSIG; e += 64) Pu[e] = 0.f;
             // The table base is re-declared opaque (a scalar register pair) in every iteration: otherwise the compiler hoists
             // the several hundred per-lane 64-bit load addresses of the unrolled chains out of the loop and spills them all.
-            const float* Abase = Abase0;
-            asm volatile("" : "+s"(Abase));
+            // The opaque copy loses the pointer's address space; it is cast back to GLOBAL explicitly: a generic (flat) load
+            // also counts on the LDS counter, so waiting for an LDS operand would wait for every table load in flight and
+            // the prefetch of the next block pair would never overlap the MFMA chain of this one.
+            typedef const float __attribute__((address_space(1))) * gfloat_p;
+            const float* Abase_generic = Abase0;
+            asm volatile("" : "+s"(Abase_generic));
+            const gfloat_p Abase = (gfloat_p)Abase_generic;
 
             // ---- pass A: per output block H X and (H.H) s, then the per-(window, tap) algebra that does not need e
             float zP[NB][8], zQ[NB][8], al[NB][8], be[NB][8], zz[NB][8], dvv[NB][8];
             float a0 = 0.f, a1 = 0.f, q0 = 0.f, q1 = 0.f, sd0 = 0.f, sd1 = 0.f, vs = 0.f;
-            // the A operands of block pair p + 1 are requested before the MFMA chain of pair p is issued; the empty asm
-            // statements keep the compiler from hoisting more than that one pair of loads (register budget)
-            float cur[24], nxt[24];
+            // the A operands of block pair p + 1 are requested before the MFMA chain of pair p is issued; sched_barrier keeps
+            // the compiler from hoisting more than that one pair of loads (register budget)
+            float abuf[2][24];   // two register sets, alternating by block pair: no copies
 #pragma unroll
-            for (int s = 0; s < 24; ++s) cur[s] = Abase[s * 64 + ulane];
+            for (int s = 0; s < 24; ++s) abuf[0][s] = Abase[s * 64 + ulane];
 #pragma unroll
             for (int xb = 0; xb < NB; ++xb) {
                 f32x16 U, TT;
@@ -247,22 +252,21 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                 for (int g = 0; g < 16; ++g) { U[g] = 0.f; TT[g] = 0.f; }
 #pragma unroll
                 for (int jb = 0; jb < NB; ++jb) {
-                    asm volatile("" ::: "memory");
-                    if (xb * NB + jb + 1 < NB * NB) {
-                        const float* A = Abase + (size_t)(xb * NB + jb + 1) * 40 * 64;
+                    const int pr = xb * NB + jb;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (pr + 1 < NB * NB) {
+                        const gfloat_p A = Abase + (size_t)(pr + 1) * 40 * 64;
 #pragma unroll
-                        for (int s = 0; s < 24; ++s) nxt[s] = A[s * 64 + ulane];
+                        for (int s = 0; s < 24; ++s) abuf[(pr + 1) & 1][s] = A[s * 64 + ulane];
                     }
-                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int s = 0; s < 16; ++s) {
                         const int k = 2 * s + h;
-                        U = MFMA32(cur[s], s_mu[(k >> 4) * MS + tsl + i + 16 * jb + (k & 15)], U);
+                        U = MFMA32(abuf[pr & 1][s], s_mu[(k >> 4) * MS + tsl + i + 16 * jb + (k & 15)], U);
                     }
 #pragma unroll
-                    for (int s = 0; s < 8; ++s) TT = MFMA32(cur[16 + s], s_S[tsl + i + 16 * jb + 2 * s + h], TT);
-#pragma unroll
-                    for (int s = 0; s < 24; ++s) cur[s] = nxt[s];
+                    for (int s = 0; s < 8; ++s) TT = MFMA32(abuf[pr & 1][16 + s], s_S[tsl + i + 16 * jb + 2 * s + h], TT);
                 }
                 BSTAMP(1);
 #pragma unroll
@@ -305,9 +309,9 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
             e0 *= mv; e1 *= mv;
 
             // ---- pass B: per output block H w, the anti-diagonal sums of the moment gradients, dE/dH
-            float curh[16], nxth[16];
+            float hbuf[2][16];
 #pragma unroll
-            for (int s = 0; s < 16; ++s) curh[s] = Abase[(24 + s) * 64 + ulane];
+            for (int s = 0; s < 16; ++s) hbuf[0][s] = Abase[(24 + s) * 64 + ulane];
 #pragma unroll
             for (int xb = 0; xb < NB; ++xb) {
                 f32x16 HW;
@@ -315,17 +319,16 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                 for (int g = 0; g < 16; ++g) HW[g] = 0.f;
 #pragma unroll
                 for (int jb = 0; jb < NB; ++jb) {
-                    asm volatile("" ::: "memory");
-                    if (xb * NB + jb + 1 < NB * NB) {
-                        const float* A = Abase + ((size_t)(xb * NB + jb + 1) * 40 + 24) * 64;
+                    const int pr = xb * NB + jb;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (pr + 1 < NB * NB) {
+                        const gfloat_p A = Abase + ((size_t)(pr + 1) * 40 + 24) * 64;
 #pragma unroll
-                        for (int s = 0; s < 16; ++s) nxth[s] = A[s * 64 + ulane];
+                        for (int s = 0; s < 16; ++s) hbuf[(pr + 1) & 1][s] = A[s * 64 + ulane];
                     }
-                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int s = 0; s < 16; ++s) HW = MFMA32(curh[s], s < 8 ? al[jb][s & 7] : be[jb][s & 7], HW);
-#pragma unroll
-                    for (int s = 0; s < 16; ++s) curh[s] = nxth[s];
+                    for (int s = 0; s < 16; ++s) HW = MFMA32(hbuf[pr & 1][s], s < 8 ? al[jb][s & 7] : be[jb][s & 7], HW);
                 }
                 BSTAMP(3);
                 // anti-diagonal sums (symbol = window + tap) of the moment gradients, one pair of quantities per round, by lane
