@@ -92,6 +92,9 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
     float* s_T = s_c + S * 4 * LEB;            // [NW][32 * TP]  transposing buffer of rho / sigma
     float* s_P = s_T + NW * 32 * TP;           // [S][NU][6][NSIG] anti-diagonal partial sums
     float* s_rec = s_P + S * NU * 6 * NSIG;    // [S][REC]
+    // per-wave parking area for two of the six per-(window, tap) arrays that live from pass A to pass B (|z|^2 + 4 T and
+    // v_a - v_b): 48 registers per lane that would otherwise spill to scratch memory; [NW][2][NB * 8][64 lanes]
+    float* s_park = s_rec + S * REC;
     __shared__ double dred[NW];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -100,6 +103,8 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
     // base per wave instead of one 64-bit address per lane and load)
     const int r = __builtin_amdgcn_readfirstlane(wv / NWP), wsub = __builtin_amdgcn_readfirstlane(wv % NWP);
     float* Tb = s_T + wv * 32 * TP;
+    float* park_zz = s_park + (size_t)wv * 2 * NB * 8 * 64 + lane;
+    float* park_dv = park_zz + NB * 8 * 64;
     const float* __restrict__ mom = ws + l.o_mom;
     float* __restrict__ gmom = ws + l.o_gmom;
     const int64_t own_hi = l.own_lo + l.own_cnt, sym_hi = l.sym_lo + l.sym_cnt;
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
             const gfloat_p Abase = (gfloat_p)Abase_generic;
 
             // ---- pass A: per output block H X and (H.H) s, then the per-(window, tap) algebra that does not need e
-            float zP[NB][8], zQ[NB][8], al[NB][8], be[NB][8], zz[NB][8], dvv[NB][8];
+            float zP[NB][8], zQ[NB][8], al[NB][8], be[NB][8];
             float a0 = 0.f, a1 = 0.f, q0 = 0.f, q1 = 0.f, sd0 = 0.f, sd1 = 0.f, vs = 0.f;
             // the A operands of block pair p + 1 are requested before the MFMA chain of pair p is issued; sched_barrier keeps
             // the compiler from hoisting more than that one pair of loads (register budget)
@@ -292,8 +297,8 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                     al[xb][q] = 2.f * Sv * zp + 2.f * (ka * dr - kb * di);
                     be[xb][q] = 2.f * Sv * zq + 2.f * (ka * di + kb * dr);
                     zP[xb][q] = zp; zQ[xb][q] = zq;
-                    zz[xb][q] = z2 + 4.f * T;
-                    dvv[xb][q] = dv;
+                    park_zz[(xb * 8 + q) * 64] = z2 + 4.f * T;
+                    park_dv[(xb * 8 + q) * 64] = dv;
                     gdr[xb][q] += mo * (2.f * (ka * zp + kb * zq) + 2.f * gs * dr);
                     gdi[xb][q] += mo * (2.f * (ka * zq - kb * zp) + 2.f * gs * di);
                 }
@@ -345,8 +350,9 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                             db[q] = 2.f * (e1 * zp - e0 * zq) + 2.f * HW[q + 8];
                         } else if (round == 1) {
                             const float ed = 2.f * (e0 * dr + e1 * di);
-                            da[q] = zz[xb][q] + ed;
-                            db[q] = zz[xb][q] - ed;
+                            const float zzq = park_zz[(xb * 8 + q) * 64];
+                            da[q] = zzq + ed;
+                            db[q] = zzq - ed;
                         } else {
                             da[q] = 2.f * (dr * zp + di * zq);
                             db[q] = 2.f * (dr * zq - di * zp);
@@ -370,8 +376,9 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                     const float gr = 2.f * (e0 * ma + e1 * mb), gi = 2.f * (e1 * ma - e0 * mb);
                     ghr[xb][q] += mo * (gr + al[xb][q]);
                     ghi[xb][q] += mo * (gi + be[xb][q]);
-                    gdr[xb][q] += mo * 2.f * e0 * dvv[xb][q];
-                    gdi[xb][q] += mo * 2.f * e1 * dvv[xb][q];
+                    const float dvq = park_dv[(xb * 8 + q) * 64];
+                    gdr[xb][q] += mo * 2.f * e0 * dvq;
+                    gdi[xb][q] += mo * 2.f * e1 * dvq;
                     Tb[i * TP + xl] = mo * (gr + 2.f * al[xb][q]);
                     Tb[i * TP + 16 + xl] = mo * (gi + 2.f * be[xb][q]);
                 }

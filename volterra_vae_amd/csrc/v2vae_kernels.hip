@@ -144,7 +144,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
             l.nblk_cxb = l.ntile_cxb < CX_BLOCKS ? l.ntile_cxb : CX_BLOCKS;
             const int ms = CXB_TWB + l.cxb_leb + 16, nsig = 32 + l.cxb_leb;
             l.lds_cxb = ((11 * ms + 2 * l.S * CXB_TWB) + l.S * 4 * l.cxb_leb + 4 * 32 * CX_TP +
-                         l.S * (CXB_TWB / 32) * 6 * nsig + l.S * l.cxb_rec) * 4;
+                         l.S * (CXB_TWB / 32) * 6 * nsig + l.S * l.cxb_rec + 4 * 2 * l.cxb_nb * 8 * 64) * 4;
         }
         l.nblk_E = l.use_cx ? l.nblk_cx : (l.use_cxb ? l.nblk_cxb : l.nblk_elbo);
         if (!l.use_cx && !l.use_cxb && !generic_elbo_ok) return V2VAE_ESIZE;
