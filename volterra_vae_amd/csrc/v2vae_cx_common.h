@@ -45,7 +45,7 @@ __device__ __forceinline__ float cx_antidiag(const float (&v)[8]) {
         // assembly because the compiler's builtin returns its first result twice when the second operand is a zero; the
         // s_nop cover the VALU-write -> permlane-swap hazards the compiler cannot see inside the statement.
         float x = v[q], z = 0.f;
-        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(z));
+        asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(z));  // not volatile: free to interleave
         lo[q] = x;
         hi[q] = z;
     }
