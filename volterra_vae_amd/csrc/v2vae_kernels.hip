@@ -1386,10 +1386,14 @@ __global__ __launch_bounds__(NT) void k_adam(int64_t n, float* __restrict__ p, c
 // parameters, optimiser state) goes through pointers that are made opaque per-lane values here, so those reads
 // are ordinary vector loads ordered by the workgroup barriers between stages; only the never-written inputs
 // (samples, levels, prior, schedule) keep wave-uniform addresses.
+// The opaque copy is made of the pointer typed as GLOBAL, so the accesses stay global_load / global_store (a generic "flat"
+// access also counts on the LDS counter, so every wait for an LDS operand would wait for it too).
 template <typename T>
 __device__ __forceinline__ T* per_lane(T* p) {
-    asm volatile("" : "+v"(p));
-    return p;
+    typedef T __attribute__((address_space(1))) * gptr;
+    gptr g = (gptr)p;
+    asm volatile("" : "+v"(g));
+    return (T*)g;
 }
 
 template <int CB, int MAXI_EQ>
