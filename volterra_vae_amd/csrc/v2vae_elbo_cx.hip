@@ -58,7 +58,13 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
     // that window index -15..47 of any row reads either data or zeros
     constexpr int ADB = 16 + 16 * 48;
     float* s_B = s_T + NW * 32 * TP;           // [NW waves][2][ADB]
-    float* s_P = s_B + NW * 2 * ADB;           // [S][NU][6][NSIG]
+    float* s_P = s_B + NW * 2 * ADB;           // [S][NU][4][NSIG]
+    // The gradient of E with respect to the 3rd central moments is LINEAR in the means with constant coefficients:
+    //   g_a + i g_b at symbol m = 2 sum_{r,x} conj(d_x) z_{m-x,x},  z_{n,x} = h_x + 2 sum_j H_xj mu_{n+j}
+    //                          = K0 + 4 sum_lag C[lag] mu_{m+lag},   C[lag] = sum_r sum_{j-x=lag} conj(d_x) H_xj,
+    // a 31-tap complex correlation per symbol instead of a third anti-diagonal round per window slab.
+    float* s_fir = s_P + S * NU * 4 * NSIG;    // [32] (Re, Im) pairs: C at index lag + 15, K0 at index 31
+    float* s_g2 = s_fir + 64;                  // [2][TWB] that gradient for the symbols this tile owns
     __shared__ double dred[CX2_NT / 64];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -122,6 +128,29 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
             t += dr * dr + di * di;
         }
         dd_sum[rr] = t;
+    }
+    if (tid < 32) {
+        const int lag = tid - 15;  // tid 31: the constant term K0 = 2 sum conj(d_x) h_x
+        float cr = 0.f, ci = 0.f;
+        for (int rr = 0; rr < S; ++rr) {
+            const float* Hr = ws + l.o_cxH + (size_t)(rr * 2 + 0) * 256;
+            const float* Hi = ws + l.o_cxH + (size_t)(rr * 2 + 1) * 256;
+            const float* cc = s_c + rr * 64;
+            for (int x = 0; x < 16; ++x) {
+                const float dr = cc[2 * 16 + x], di = cc[3 * 16 + x];
+                float ar, ai;
+                if (tid == 31) { ar = 2.f * cc[x]; ai = 2.f * cc[16 + x]; }
+                else {
+                    const int j = x + lag;
+                    if (j < 0 || j > 15) continue;
+                    ar = Hr[x * 16 + j]; ai = Hi[x * 16 + j];
+                }
+                cr += dr * ar + di * ai;   // conj(d) * a
+                ci += dr * ai - di * ar;
+            }
+        }
+        s_fir[2 * tid] = cr;
+        s_fir[2 * tid + 1] = ci;
     }
 
 #ifdef V2VAE_STAMPS
@@ -219,6 +248,53 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
         const float* s_yw = s_stage + 7 * MS;
         const bool more = tile + (int)gridDim.x < l.ntile_cx;
         if (more) stage_load(tile + gridDim.x);
+        // third-moment gradient of the owned symbols by the correlation above (edge symbols, whose windows do not all
+        // exist, by the explicit double sum)
+        for (int ml = tid; ml < TS; ml += CX2_NT) {   // one thread per symbol, both components
+            const int64_t m = s0 + ml;
+            if (m < s1) {
+                const int ms = ml + l.kmax;
+                float gr, gi;
+                if ((m - l.kmax) >= 0 && (m * S + S - 1) < l.W) {
+                    const float* ma = s_mu + ms - 15;
+                    const float* mb = ma + MS;
+                    const f2* cf = reinterpret_cast<const f2*>(s_fir);   // (Re, Im) pairs
+                    float ar = 0.f, ai = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 31; ++t) {
+                        const f2 cc = cf[t];
+                        const float ua = ma[t], ub = mb[t];
+                        ar += cc.x * ua - cc.y * ub;
+                        ai += cc.x * ub + cc.y * ua;
+                    }
+                    const f2 k0 = cf[31];
+                    gr = k0.x + 4.f * ar; gi = k0.y + 4.f * ai;
+                } else {
+                    gr = 0.f; gi = 0.f;
+                    for (int rr = 0; rr < S; ++rr) {
+                        const float* Hr = ws + l.o_cxH + (size_t)(rr * 2 + 0) * 256;
+                        const float* Hi = ws + l.o_cxH + (size_t)(rr * 2 + 1) * 256;
+                        const float* cc = s_c + rr * 64;
+                        for (int x = 0; x < l.LE; ++x) {
+                            const int64_t n = (m - x) * S + rr;
+                            if (n < 0 || n >= l.W) continue;
+                            float zr = cc[x], zi = cc[16 + x];
+                            for (int j = 0; j < l.LE; ++j) {
+                                const float hr = Hr[x * 16 + j], hi = Hi[x * 16 + j];
+                                const float ua = s_mu[ms - x + j], ub = s_mu[MS + ms - x + j];
+                                zr += 2.f * (hr * ua - hi * ub);
+                                zi += 2.f * (hi * ua + hr * ub);
+                            }
+                            const float dr = cc[2 * 16 + x], di = cc[3 * 16 + x];
+                            gr += 2.f * (dr * zr + di * zi);
+                            gi += 2.f * (dr * zi - di * zr);
+                        }
+                    }
+                }
+                s_g2[ml] = gr;
+                s_g2[TWB + ml] = gi;
+            }
+        }
         STAMP(0);
 
         for (int sub = wsub; sub < NU; sub += NWP) {
@@ -306,13 +382,13 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
             // ---- anti-diagonal sums of the moment gradients (symbol = window + tap), one quantity per round through
             //      the wave's zero-padded buffer.  LDS instructions of one wave execute in program order, so lanes may
             //      read what other lanes of the same wave wrote earlier; wave_barrier only pins the compiler's ordering.
-            float* Pu = s_P + ((size_t)(r * NU + sub) * 6) * NSIG;
+            float* Pu = s_P + ((size_t)(r * NU + sub) * 4) * NSIG;
 #ifdef ABLATE_ANTIDIAG
 #pragma unroll
             for (int q = 0; q < 8; ++q) asm volatile("" ::"v"(HW[q]), "v"(HW[q + 8]), "v"(zz[q >> 1][q & 1]));
 #else
 #pragma unroll
-            for (int round = 0; round < 3; ++round) {
+            for (int round = 0; round < 2; ++round) {   // the third quantity pair (3rd-moment gradient) is a correlation, see s_fir
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     const int x = cx_kk(2 * p, h);
@@ -321,13 +397,10 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
                     if (round == 0) {
                         da = 2.f * (e0 * zp + e1 * zq + f2{HW[2 * p], HW[2 * p + 1]});
                         db = 2.f * (e1 * zp - e0 * zq + f2{HW[2 * p + 8], HW[2 * p + 9]});
-                    } else if (round == 1) {
+                    } else {
                         const f2 ed = 2.f * (e0 * dr + e1 * di);
                         da = zz[p] + ed;
                         db = zz[p] - ed;
-                    } else {
-                        da = 2.f * (dr * zp + di * zq);
-                        db = 2.f * (dr * zq - di * zp);
                     }
                     da *= mv;
                     db *= mv;
@@ -394,17 +467,18 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
                 const int ms = ml + l.kmax;
                 const int sub_hi = ms >> 5, sg_hi = ms & 31;
                 const bool two = (sg_hi + 32 < 32 + l.LE - 1) && sub_hi > 0;
-                float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+                float g0 = 0.f, g1 = 0.f, g3 = 0.f;
+                const float g2 = s_g2[c * TWB + ml];
                 // every window that holds this symbol exists: (m - kmax) * S >= 0 and m * S + S - 1 < W
                 const bool interior = (m - l.kmax) >= 0 && (m * S + S - 1) < l.W;
                 for (int rr = 0; rr < S; ++rr) {
                     if (two) {
-                        const float* P = s_P + ((size_t)(rr * NU + sub_hi - 1) * 6) * NSIG + sg_hi + 32;
-                        g0 += P[(0 + c) * NSIG]; g1 += P[(2 + c) * NSIG]; g2 += P[(4 + c) * NSIG];
+                        const float* P = s_P + ((size_t)(rr * NU + sub_hi - 1) * 4) * NSIG + sg_hi + 32;
+                        g0 += P[(0 + c) * NSIG]; g1 += P[(2 + c) * NSIG];
                     }
                     if (sub_hi < NU) {
-                        const float* P = s_P + ((size_t)(rr * NU + sub_hi) * 6) * NSIG + sg_hi;
-                        g0 += P[(0 + c) * NSIG]; g1 += P[(2 + c) * NSIG]; g2 += P[(4 + c) * NSIG];
+                        const float* P = s_P + ((size_t)(rr * NU + sub_hi) * 4) * NSIG + sg_hi;
+                        g0 += P[(0 + c) * NSIG]; g1 += P[(2 + c) * NSIG];
                     }
                     if (interior) g3 += dd_sum[rr];
                     else
