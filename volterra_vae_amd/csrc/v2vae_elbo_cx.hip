@@ -59,12 +59,6 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
     constexpr int ADB = 16 + 16 * 48;
     float* s_B = s_T + NW * 32 * TP;           // [NW waves][2][ADB]
     float* s_P = s_B + NW * 2 * ADB;           // [S][NU][4][NSIG]
-    // The gradient of E with respect to the 3rd central moments is LINEAR in the means with constant coefficients:
-    //   g_a + i g_b at symbol m = 2 sum_{r,x} conj(d_x) z_{m-x,x},  z_{n,x} = h_x + 2 sum_j H_xj mu_{n+j}
-    //                          = K0 + 4 sum_lag C[lag] mu_{m+lag},   C[lag] = sum_r sum_{j-x=lag} conj(d_x) H_xj,
-    // a 31-tap complex correlation per symbol instead of a third anti-diagonal round per window slab.
-    float* s_fir = s_P + S * NU * 4 * NSIG;    // [32] (Re, Im) pairs: C at index lag + 15, K0 at index 31
-    float* s_g2 = s_fir + 64;                  // [2][TWB] that gradient for the symbols this tile owns
     __shared__ double dred[CX2_NT / 64];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -119,39 +113,6 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
     // the same for the tap pair (2 p, 2 p + 1): neighbouring taps, neighbouring addresses
 #define C2(row, p) ld2(cst + (row) * 16 + ((2 * (p)) & 3) + 8 * ((2 * (p)) >> 2))
     __syncthreads();
-    float dd_sum[S];
-#pragma unroll
-    for (int rr = 0; rr < S; ++rr) {
-        float t = 0.f;
-        for (int kk = 0; kk < l.LE; ++kk) {
-            const float dr = s_c[rr * 64 + 2 * 16 + kk], di = s_c[rr * 64 + 3 * 16 + kk];
-            t += dr * dr + di * di;
-        }
-        dd_sum[rr] = t;
-    }
-    if (tid < 32) {
-        const int lag = tid - 15;  // tid 31: the constant term K0 = 2 sum conj(d_x) h_x
-        float cr = 0.f, ci = 0.f;
-        for (int rr = 0; rr < S; ++rr) {
-            const float* Hr = ws + l.o_cxH + (size_t)(rr * 2 + 0) * 256;
-            const float* Hi = ws + l.o_cxH + (size_t)(rr * 2 + 1) * 256;
-            const float* cc = s_c + rr * 64;
-            for (int x = 0; x < 16; ++x) {
-                const float dr = cc[2 * 16 + x], di = cc[3 * 16 + x];
-                float ar, ai;
-                if (tid == 31) { ar = 2.f * cc[x]; ai = 2.f * cc[16 + x]; }
-                else {
-                    const int j = x + lag;
-                    if (j < 0 || j > 15) continue;
-                    ar = Hr[x * 16 + j]; ai = Hi[x * 16 + j];
-                }
-                cr += dr * ar + di * ai;   // conj(d) * a
-                ci += dr * ai - di * ar;
-            }
-        }
-        s_fir[2 * tid] = cr;
-        s_fir[2 * tid + 1] = ci;
-    }
 
 #ifdef V2VAE_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
@@ -248,53 +209,6 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
         const float* s_yw = s_stage + 7 * MS;
         const bool more = tile + (int)gridDim.x < l.ntile_cx;
         if (more) stage_load(tile + gridDim.x);
-        // third-moment gradient of the owned symbols by the correlation above (edge symbols, whose windows do not all
-        // exist, by the explicit double sum)
-        for (int ml = tid; ml < TS; ml += CX2_NT) {   // one thread per symbol, both components
-            const int64_t m = s0 + ml;
-            if (m < s1) {
-                const int ms = ml + l.kmax;
-                float gr, gi;
-                if ((m - l.kmax) >= 0 && (m * S + S - 1) < l.W) {
-                    const float* ma = s_mu + ms - 15;
-                    const float* mb = ma + MS;
-                    const f2* cf = reinterpret_cast<const f2*>(s_fir);   // (Re, Im) pairs
-                    float ar = 0.f, ai = 0.f;
-#pragma unroll
-                    for (int t = 0; t < 31; ++t) {
-                        const f2 cc = cf[t];
-                        const float ua = ma[t], ub = mb[t];
-                        ar += cc.x * ua - cc.y * ub;
-                        ai += cc.x * ub + cc.y * ua;
-                    }
-                    const f2 k0 = cf[31];
-                    gr = k0.x + 4.f * ar; gi = k0.y + 4.f * ai;
-                } else {
-                    gr = 0.f; gi = 0.f;
-                    for (int rr = 0; rr < S; ++rr) {
-                        const float* Hr = ws + l.o_cxH + (size_t)(rr * 2 + 0) * 256;
-                        const float* Hi = ws + l.o_cxH + (size_t)(rr * 2 + 1) * 256;
-                        const float* cc = s_c + rr * 64;
-                        for (int x = 0; x < l.LE; ++x) {
-                            const int64_t n = (m - x) * S + rr;
-                            if (n < 0 || n >= l.W) continue;
-                            float zr = cc[x], zi = cc[16 + x];
-                            for (int j = 0; j < l.LE; ++j) {
-                                const float hr = Hr[x * 16 + j], hi = Hi[x * 16 + j];
-                                const float ua = s_mu[ms - x + j], ub = s_mu[MS + ms - x + j];
-                                zr += 2.f * (hr * ua - hi * ub);
-                                zi += 2.f * (hi * ua + hr * ub);
-                            }
-                            const float dr = cc[2 * 16 + x], di = cc[3 * 16 + x];
-                            gr += 2.f * (dr * zr + di * zi);
-                            gi += 2.f * (dr * zi - di * zr);
-                        }
-                    }
-                }
-                s_g2[ml] = gr;
-                s_g2[TWB + ml] = gi;
-            }
-        }
         STAMP(0);
 
         for (int sub = wsub; sub < NU; sub += NWP) {
@@ -388,7 +302,7 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
             for (int q = 0; q < 8; ++q) asm volatile("" ::"v"(HW[q]), "v"(HW[q + 8]), "v"(zz[q >> 1][q & 1]));
 #else
 #pragma unroll
-            for (int round = 0; round < 2; ++round) {   // the third quantity pair (3rd-moment gradient) is a correlation, see s_fir
+            for (int round = 0; round < 2; ++round) {   // gradients of the means, then of the variances (the other two: k_g2_cx)
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     const int x = cx_kk(2 * p, h);
@@ -467,10 +381,7 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
                 const int ms = ml + l.kmax;
                 const int sub_hi = ms >> 5, sg_hi = ms & 31;
                 const bool two = (sg_hi + 32 < 32 + l.LE - 1) && sub_hi > 0;
-                float g0 = 0.f, g1 = 0.f, g3 = 0.f;
-                const float g2 = s_g2[c * TWB + ml];
-                // every window that holds this symbol exists: (m - kmax) * S >= 0 and m * S + S - 1 < W
-                const bool interior = (m - l.kmax) >= 0 && (m * S + S - 1) < l.W;
+                float g0 = 0.f, g1 = 0.f;
                 for (int rr = 0; rr < S; ++rr) {
                     if (two) {
                         const float* P = s_P + ((size_t)(rr * NU + sub_hi - 1) * 4) * NSIG + sg_hi + 32;
@@ -480,18 +391,9 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
                         const float* P = s_P + ((size_t)(rr * NU + sub_hi) * 4) * NSIG + sg_hi;
                         g0 += P[(0 + c) * NSIG]; g1 += P[(2 + c) * NSIG];
                     }
-                    if (interior) g3 += dd_sum[rr];
-                    else
-                        for (int kk = 0; kk < l.LE; ++kk) {
-                            const int64_t t = m - kk, n = t * S + rr;
-                            if (n >= 0 && n < l.W) {
-                                const float dr = s_c[rr * 64 + 2 * 16 + kk], di = s_c[rr * 64 + 3 * 16 + kk];
-                                g3 += dr * dr + di * di;
-                            }
-                        }
                 }
                 float* gp = gmom + (int64_t)c * 4 * l.sym_cnt + (m - l.sym_lo);
-                gp[0] = g0; gp[l.sym_cnt] = g1; gp[2 * l.sym_cnt] = g2; gp[3 * l.sym_cnt] = g3;
+                gp[0] = g0; gp[l.sym_cnt] = g1;   // planes 2 and 3: k_g2_cx
             }
         }
         __syncthreads();
@@ -598,6 +500,128 @@ __global__ __launch_bounds__(NT) void k_psum_cx(Lay l, float* __restrict__ ws) {
     }
 }
 
+// Gradient of E with respect to the 3rd central moments and the 4th cumulants of every owned symbol, right after the soft
+// demapper.  The former is LINEAR in the means with constant coefficients,
+//   g_a + i g_b at symbol m = 2 sum_{r,x} conj(d_x) z_{m-x,x},   z_{n,x} = h_x + 2 sum_j H_xj mu_{n+j}
+//                          = K0 + 4 sum_lag C[lag] mu_{m+lag},    C[lag] = sum_r sum_{j-x=lag} conj(d_x) H_xj,
+// a (2 Le - 1)-tap complex correlation per symbol, and the latter is the constant sum |d_x|^2 - for symbols all of whose
+// windows exist.  The few symbols at the two ends of the sequence take the explicit sums over the windows that do exist.
+// So the ELBO kernels only form the gradients with respect to means and variances (which need the residual).
+constexpr int G2_TILE = 4 * NT;         // symbols per tile: four consecutive symbols per thread
+
+template <int NLAG>
+__global__ __launch_bounds__(NT) void k_g2_cx(Lay l, float* __restrict__ ws) {
+    constexpr int HALO = NLAG + 8;                     // staged means on either side of the tile
+    constexpr int PL = (G2_TILE + 2 * HALO) / 4;       // the staged means are kept as four planes by (index mod 4): a
+                                                       // thread owns four consecutive symbols and every read is unit-stride
+    __shared__ float s_mq[2][4][PL];
+    __shared__ float s_cf[4 + 2 * (2 * NLAG + 8)];
+    __shared__ float s_e[NT / 64][3];
+    __shared__ float s_out[2][4][NT];                  // results, for coalesced stores
+    const float* __restrict__ mom = ws + l.o_mom;
+    float* __restrict__ gmom = ws + l.o_gmom;
+    const int64_t own_hi = l.own_lo + l.own_cnt, sym_hi = l.sym_lo + l.sym_cnt, st = l.sym_cnt;
+    const int S = l.S;
+    const int K4 = (l.kmax + 3) & ~3, ntap = 2 * K4 + 4;
+    for (int i = threadIdx.x; i < 4 + 2 * ntap; i += NT) s_cf[i] = ws[l.o_g2c + i];
+    const int64_t ntile = (l.own_cnt + G2_TILE - 1) / G2_TILE;
+    for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int64_t m0 = l.own_lo + tile * G2_TILE;
+        __syncthreads();
+        for (int e = threadIdx.x; e < G2_TILE + 2 * HALO; e += NT) {
+            const int64_t m = m0 - HALO + e;
+            const bool in = m >= l.sym_lo && m < sym_hi;
+            s_mq[0][e & 3][e >> 2] = in ? mom[m - l.sym_lo] : 0.f;
+            s_mq[1][e & 3][e >> 2] = in ? mom[4 * st + (m - l.sym_lo)] : 0.f;
+        }
+        __syncthreads();
+        // thread t owns symbols m0 + 4 t .. + 3; the window of means slides through registers
+        const int q0 = (HALO - K4) / 4 + threadIdx.x;    // first quad of the window (HALO and K4 are multiples of 4)
+        float wa[8], wb[8], ar[4], ai[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { wa[k] = s_mq[0][k][q0]; wb[k] = s_mq[1][k][q0]; ar[k] = 0.f; ai[k] = 0.f; }
+        for (int g = 0; g < ntap / 4; ++g) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { wa[4 + k] = s_mq[0][k][q0 + g + 1]; wb[4 + k] = s_mq[1][k][q0 + g + 1]; }
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const f2 cc = ld2(s_cf + 4 + 2 * (4 * g + tt));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    ar[k] = fmaf(cc.x, wa[tt + k], ar[k]); ar[k] = fmaf(-cc.y, wb[tt + k], ar[k]);
+                    ai[k] = fmaf(cc.x, wb[tt + k], ai[k]); ai[k] = fmaf(cc.y, wa[tt + k], ai[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { wa[k] = wa[4 + k]; wb[k] = wb[4 + k]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s_out[0][k][threadIdx.x] = ar[k]; s_out[1][k][threadIdx.x] = ai[k]; }
+        __syncthreads();
+        const float k0r = s_cf[0], k0i = s_cf[1], g3c = s_cf[2];
+        for (int i = threadIdx.x; i < G2_TILE; i += NT) {
+            const int64_t m = m0 + i;
+            // every window that holds this symbol exists: (m - kmax) * S >= 0 and m * S + S - 1 < W
+            if (m < own_hi && m >= l.kmax && m * S + S - 1 < l.W) {
+                float* gp = gmom + (m - l.sym_lo);
+                gp[2 * st] = fmaf(4.f, s_out[0][i & 3][i >> 2], k0r);
+                gp[6 * st] = fmaf(4.f, s_out[1][i & 3][i >> 2], k0i);
+                gp[3 * st] = g3c;
+                gp[7 * st] = g3c;
+            }
+        }
+    }
+
+    // ---- symbols at the ends of the sequence: m < kmax, or m >= W / S (some window (m - x) S + r does not exist); one
+    //      workgroup per symbol, threads over (phase, tap, tap)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t tail0 = l.W > 0 ? l.W / S : 0;
+    const int64_t head_hi = own_hi < l.kmax ? own_hi : l.kmax;
+    const int64_t nh = head_hi > l.own_lo ? head_hi - l.own_lo : 0;
+    int64_t t0 = tail0 > l.kmax ? tail0 : l.kmax;
+    if (t0 < l.own_lo) t0 = l.own_lo;
+    const int64_t nt = own_hi > t0 ? own_hi - t0 : 0;
+    const int LE = l.LE, LTp = l.LTp;
+    for (int64_t e = blockIdx.x; e < nh + nt; e += gridDim.x) {
+        const int64_t m = e < nh ? l.own_lo + e : t0 + (e - nh);
+        float gr = 0.f, gi = 0.f, g3 = 0.f;
+        for (int it = threadIdx.x; it < S * LE * LE; it += NT) {
+            const int r = it / (LE * LE), rem = it - r * LE * LE;
+            const int x = rem / LE, j = rem - x * LE;
+            const int64_t n = (m - x) * S + r;
+            if (n < 0 || n >= l.W) continue;
+            const float* Hr = ws + l.o_Hc + (size_t)(r * 2 + 0) * LTp * LTp;
+            const float* Hi = ws + l.o_Hc + (size_t)(r * 2 + 1) * LTp * LTp;
+            const float dr = Hr[x * LTp + x], di = Hi[x * LTp + x];
+            const float hr = Hr[x * LTp + j], hi = Hi[x * LTp + j];
+            const int64_t mm = m - x + j;
+            float ua = 0.f, ub = 0.f;
+            if (mm >= l.sym_lo && mm < sym_hi) { ua = mom[mm - l.sym_lo]; ub = mom[4 * st + (mm - l.sym_lo)]; }
+            const float cr = hr * ua - hi * ub, ci = hi * ua + hr * ub;
+            gr += 4.f * (dr * cr + di * ci);
+            gi += 4.f * (dr * ci - di * cr);
+            if (j == 0) {
+                const float h1r = ws[l.o_h1c + (size_t)(r * 2 + 0) * LTp + x], h1i = ws[l.o_h1c + (size_t)(r * 2 + 1) * LTp + x];
+                gr += 2.f * (dr * h1r + di * h1i);
+                gi += 2.f * (dr * h1i - di * h1r);
+                g3 += dr * dr + di * di;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            gr += __shfl_down(gr, off, 64); gi += __shfl_down(gi, off, 64); g3 += __shfl_down(g3, off, 64);
+        }
+        __syncthreads();
+        if (lane == 0) { s_e[wv][0] = gr; s_e[wv][1] = gi; s_e[wv][2] = g3; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float a = 0.f, b = 0.f, c = 0.f;
+            for (int w = 0; w < NT / 64; ++w) { a += s_e[w][0]; b += s_e[w][1]; c += s_e[w][2]; }
+            float* gp = gmom + (m - l.sym_lo);
+            gp[2 * st] = a; gp[6 * st] = b; gp[3 * st] = c; gp[7 * st] = c;
+        }
+    }
+}
+
 // totals over the blocks, fixed order: thread (lag d, chunk c) sums blocks c, c + nchunk, ...; then the chunks in order
 __global__ __launch_bounds__(NT) void k_psum_finish_cx(Lay l, float* __restrict__ ws, int nlag) {
     __shared__ double red[NT];
@@ -676,14 +700,19 @@ int launch_elbo_cx(const Lay& l, const float* y, float* ws, hipStream_t st) {
     return V2VAE_OK;
 }
 
-// lagged products of s = v_a + v_b (needs only the moments, so it runs right after the soft demapper)
+// what needs only the moments and runs right after the soft demapper: lagged products of s = v_a + v_b, and the gradients
+// with respect to 3rd moments and 4th cumulants
 void launch_psum_cx(const Lay& l, float* ws, hipStream_t st) {
+    const int64_t nt = (l.own_cnt + G2_TILE - 1) / G2_TILE;
+    const int ng = (int)(nt < 4096 ? (nt > 0 ? nt : 1) : 4096);
     if (l.use_cxb) {
         hipLaunchKernelGGL(k_psum_cx<CX_MAXLAG>, dim3(l.nblk_psum), dim3(NT), 0, st, l, ws);
         hipLaunchKernelGGL(k_psum_finish_cx, dim3(1), dim3(NT), 0, st, l, ws, CX_MAXLAG);
+        hipLaunchKernelGGL(k_g2_cx<CX_MAXLAG>, dim3(ng), dim3(NT), 0, st, l, ws);
     } else {
         hipLaunchKernelGGL(k_psum_cx<16>, dim3(l.nblk_psum), dim3(NT), 0, st, l, ws);
         hipLaunchKernelGGL(k_psum_finish_cx, dim3(1), dim3(NT), 0, st, l, ws, 16);
+        hipLaunchKernelGGL(k_g2_cx<16>, dim3(ng), dim3(NT), 0, st, l, ws);
     }
 }
 

@@ -90,8 +90,8 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
     float* s_stage = sm;                       // moments float4 [2][MS] | means [2][MS] | s [MS] | y' [2][S][TWB]
     float* s_c = s_stage + STG;                // [S][4][LEB]  h1r, h1i, diag Hr, diag Hi
     float* s_T = s_c + S * 4 * LEB;            // [NW][32 * TP]  transposing buffer of rho / sigma
-    float* s_P = s_T + NW * 32 * TP;           // [S][NU][6][NSIG] anti-diagonal partial sums
-    float* s_rec = s_P + S * NU * 6 * NSIG;    // [S][REC]
+    float* s_P = s_T + NW * 32 * TP;           // [S][NU][4][NSIG] anti-diagonal partial sums
+    float* s_rec = s_P + S * NU * 4 * NSIG;    // [S][REC]
     // per-wave parking area for two of the six per-(window, tap) arrays that live from pass A to pass B (|z|^2 + 4 T and
     // v_a - v_b): 48 registers per lane that would otherwise spill to scratch memory; [NW][2][NB * 8][64 lanes]
     float* s_park = s_rec + S * REC;
@@ -116,17 +116,6 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
     const unsigned ulane = lane;
     const float* cst = s_c + r * 4 * LEB;
     __syncthreads();
-    float dd_sum[S];
-#pragma unroll
-    for (int rr = 0; rr < S; ++rr) {
-        float t = 0.f;
-        for (int kk = 0; kk < l.LE; ++kk) {
-            const float dr = s_c[(rr * 4 + 2) * LEB + kk], di = s_c[(rr * 4 + 3) * LEB + kk];
-            t += dr * dr + di * di;
-        }
-        dd_sum[rr] = t;
-    }
-
     f32x4 Gr[NB][NB], Gi[NB][NB];
     float ghr[NB][8], ghi[NB][8], gdr[NB][8], gdi[NB][8];
 #pragma unroll
@@ -230,8 +219,8 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
             const bool valid = (t < s1) && n >= 0 && n < l.W;
             const bool own = valid && t >= s0;
             const float mv = valid ? 1.f : 0.f, mo = own ? 1.f : 0.f;
-            float* Pu = s_P + ((size_t)(r * NU + sub) * 6) * NSIG;
-            for (int e = lane; e < 6 * NSIG; e += 64) Pu[e] = 0.f;
+            float* Pu = s_P + ((size_t)(r * NU + sub) * 4) * NSIG;
+            for (int e = lane; e < 4 * NSIG; e += 64) Pu[e] = 0.f;
             // The table base is re-declared opaque (a scalar register pair) in every iteration: otherwise the compiler hoists
             // the several hundred per-lane 64-bit load addresses of the unrolled chains out of the loop and spills them all.
             // The opaque copy loses the pointer's address space; it is cast back to GLOBAL explicitly: a generic (flat) load
@@ -336,10 +325,11 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                     for (int s = 0; s < 16; ++s) HW = MFMA32(hbuf[pr & 1][s], s < 8 ? al[jb][s & 7] : be[jb][s & 7], HW);
                 }
                 BSTAMP(3);
-                // anti-diagonal sums (symbol = window + tap) of the moment gradients, one pair of quantities per round, by lane
-                // shifts inside the wave (no LDS round trip); the partial of this tap block is added to the slab's record
+                // anti-diagonal sums (symbol = window + tap) of the gradients of means (round 0) and variances (round 1), by
+                // lane shifts inside the wave (no LDS round trip); the partial of this tap block is added to the slab's record.
+                // The gradients of the 3rd moments and 4th cumulants do not need the residual: k_g2_cx has written them.
 #pragma unroll
-                for (int round = 0; round < 3; ++round) {
+                for (int round = 0; round < 2; ++round) {
                     float da[8], db[8];
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
@@ -348,14 +338,11 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                         if (round == 0) {
                             da[q] = 2.f * (e0 * zp + e1 * zq) + 2.f * HW[q];
                             db[q] = 2.f * (e1 * zp - e0 * zq) + 2.f * HW[q + 8];
-                        } else if (round == 1) {
+                        } else {
                             const float ed = 2.f * (e0 * dr + e1 * di);
                             const float zzq = park_zz[(xb * 8 + q) * 64];
                             da[q] = zzq + ed;
                             db[q] = zzq - ed;
-                        } else {
-                            da[q] = 2.f * (dr * zp + di * zq);
-                            db[q] = 2.f * (dr * zq - di * zp);
                         }
                         da[q] *= mv;
                         db[q] *= mv;
@@ -417,28 +404,18 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
             const int64_t m = s0 + ml;
             if (m < s1) {
                 const int ms = ml + l.kmax;
-                float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
-                const bool interior = (m - l.kmax) >= 0 && (m * S + S - 1) < l.W;
+                float g0 = 0.f, g1 = 0.f;
                 for (int rr = 0; rr < S; ++rr) {
                     for (int d = (NSIG - 1) / 32; d >= 0; --d) {
                         const int sub = (ms >> 5) - d, sg = (ms & 31) + 32 * d;
                         if (sub >= 0 && sub < NU && sg < NSIG) {
-                            const float* P = s_P + ((size_t)(rr * NU + sub) * 6) * NSIG + sg;
-                            g0 += P[(0 + c) * NSIG]; g1 += P[(2 + c) * NSIG]; g2 += P[(4 + c) * NSIG];
+                            const float* P = s_P + ((size_t)(rr * NU + sub) * 4) * NSIG + sg;
+                            g0 += P[(0 + c) * NSIG]; g1 += P[(2 + c) * NSIG];
                         }
                     }
-                    if (interior) g3 += dd_sum[rr];
-                    else
-                        for (int kk = 0; kk < l.LE; ++kk) {
-                            const int64_t t = m - kk, n = t * S + rr;
-                            if (n >= 0 && n < l.W) {
-                                const float dr = s_c[(rr * 4 + 2) * LEB + kk], di = s_c[(rr * 4 + 3) * LEB + kk];
-                                g3 += dr * dr + di * di;
-                            }
-                        }
                 }
                 float* gp = gmom + (int64_t)c * 4 * l.sym_cnt + (m - l.sym_lo);
-                gp[0] = g0; gp[l.sym_cnt] = g1; gp[2 * l.sym_cnt] = g2; gp[3 * l.sym_cnt] = g3;
+                gp[0] = g0; gp[l.sym_cnt] = g1;   // planes 2 and 3: k_g2_cx
             }
         }
         __syncthreads();

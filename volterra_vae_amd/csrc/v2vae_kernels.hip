@@ -132,7 +132,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
         const int ts = 256 - l.kmax;
         l.ntile_cx = (int)((l.own_cnt + ts - 1) / ts);
         l.nblk_cx = l.ntile_cx < CX_BLOCKS ? l.ntile_cx : CX_BLOCKS;
-        l.lds_cx = ((7 * (256 + 48) + 2 * l.S * 256) + l.S * 40 * 64 + l.S * 64 + 8 * 32 * CX_TP + 8 * 2 * (16 + 16 * 48) + l.S * 8 * 4 * 64 + 64 + 2 * 256) * 4;
+        l.lds_cx = ((7 * (256 + 48) + 2 * l.S * 256) + l.S * 40 * 64 + l.S * 64 + 8 * 32 * CX_TP + 8 * 2 * (16 + 16 * 48) + l.S * 8 * 4 * 64) * 4;
         // blocked variant for longer channels
         l.use_cxb = (l.mode == 1 && l.LE > 16 && l.LE <= 48 && l.S <= 2 && getenv("V2VAE_FORCE_GENERIC") == nullptr) ? 1 : 0;
         l.cxb_nb = (l.LE + 15) / 16;
@@ -144,7 +144,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
             l.nblk_cxb = l.ntile_cxb < CX_BLOCKS ? l.ntile_cxb : CX_BLOCKS;
             const int ms = CXB_TWB + l.cxb_leb + 16, nsig = 32 + l.cxb_leb;
             l.lds_cxb = ((11 * ms + 2 * l.S * CXB_TWB) + l.S * 4 * l.cxb_leb + 4 * 32 * CX_TP +
-                         l.S * (CXB_TWB / 32) * 6 * nsig + l.S * l.cxb_rec + 4 * 2 * l.cxb_nb * 8 * 64) * 4;
+                         l.S * (CXB_TWB / 32) * 4 * nsig + l.S * l.cxb_rec + 4 * 2 * l.cxb_nb * 8 * 64) * 4;
         }
         l.nblk_E = l.use_cx ? l.nblk_cx : (l.use_cxb ? l.nblk_cxb : l.nblk_elbo);
         if (!l.use_cx && !l.use_cxb && !generic_elbo_ok) return V2VAE_ESIZE;
@@ -198,6 +198,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     l.o_tot_cx = take((int64_t)l.S * CX_REC);
     l.o_psum_part = take(2 * CX_MAXLAG * (int64_t)l.nblk_psum);
     l.o_psum_tot = take(2 * CX_MAXLAG);
+    l.o_g2c = take((l.use_cx || l.use_cxb) ? 4 + 2 * (2 * CX_MAXLAG + 8) : 0);
     l.o_cxbA = take(l.use_cxb ? (int64_t)l.S * l.cxb_nb * l.cxb_nb * 40 * 64 : 0);
     l.o_cxbH = take(l.use_cxb ? (int64_t)l.S * 2 * l.cxb_leb * l.cxb_leb : 0);
     l.o_cxbc = take(l.use_cxb ? (int64_t)l.S * 4 * l.cxb_leb : 0);
@@ -344,6 +345,45 @@ __device__ __forceinline__ void d_prep_tables(const GridCtx gc, Lay l, const flo
             const int r = rp / 2, pl = rp - r * 2;
             const int a = tap_index(l, r, x);
             ws[l.o_cxh1 + idx] = (x < l.LE && a >= 0) ? stacked_lin(l.mode, h1, l.L, pl, a) : 0.f;
+        }
+    }
+    if ((l.use_cx || l.use_cxb) && h1) {
+        // One wave per coefficient of the correlation form of the third-moment gradient (see k_g2_cx): with d the diagonal
+        // of the symmetrised kernel H of phase r,  C[lag] = sum_r sum_x conj(d_x) H_{x, x + lag},  K0 = 2 sum conj(d_x) h_x,
+        // and the fourth-cumulant gradient of a symbol all of whose windows exist, sum |d_x|^2.
+        const int K4 = (l.kmax + 3) & ~3, ntap = 2 * K4 + 4;
+        const int lane = threadIdx.x & 63;
+        for (int c = tid >> 6; c <= ntap; c += nth >> 6) {
+            float cr = 0.f, ci = 0.f, g3 = 0.f;
+            for (int it = lane; it < l.S * l.LE; it += 64) {
+                const int r = it / l.LE, x = it - r * l.LE;
+                const int a = tap_index(l, r, x);
+                if (a < 0) continue;
+                const float dr = stacked_quad(l.mode, h2, l.L, 0, a, a), di = stacked_quad(l.mode, h2, l.L, 1, a, a);
+                float ar, ai;
+                if (c == ntap) {
+                    ar = 2.f * stacked_lin(l.mode, h1, l.L, 0, a);
+                    ai = 2.f * stacked_lin(l.mode, h1, l.L, 1, a);
+                    g3 += dr * dr + di * di;
+                } else {
+                    const int j = x + c - K4;
+                    if (j < 0 || j >= l.LE) continue;
+                    const int b = tap_index(l, r, j);
+                    if (b < 0) continue;
+                    ar = stacked_quad(l.mode, h2, l.L, 0, a, b);
+                    ai = stacked_quad(l.mode, h2, l.L, 1, a, b);
+                }
+                cr += dr * ar + di * ai;   // conj(d) * a
+                ci += dr * ai - di * ar;
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                cr += __shfl_down(cr, off, 64); ci += __shfl_down(ci, off, 64); g3 += __shfl_down(g3, off, 64);
+            }
+            if (lane == 0) {
+                float* t = ws + l.o_g2c;
+                if (c == ntap) { t[0] = cr; t[1] = ci; t[2] = g3; t[3] = 0.f; }
+                else { t[4 + 2 * c] = cr; t[5 + 2 * c] = ci; }
+            }
         }
     }
     const int nm = l.S * l.ns * l.LTp * l.LTp;

@@ -54,6 +54,9 @@ struct Lay {
     // matrix-core ELBO path
     int use_cx, ntile_cx, nblk_cx, lds_cx, nblk_E, nblk_psum;
     int64_t o_psum_part, o_psum_tot;
+    // coefficients of the third-moment gradient as a correlation of the means (k_g2_cx): K0 (Re, Im), the constant
+    // fourth-cumulant gradient, 0, then (Re, Im) of C[lag] for lag = t - K4, t = 0 .. 2 K4 + 3, K4 = kmax rounded up to 4
+    int64_t o_g2c;
     int64_t o_cxH, o_cxh1, o_part_cx, o_tot_cx;
     // blocked matrix-core ELBO path (complex, 16 < active taps per phase <= 48): taps in blocks of 16
     int use_cxb, cxb_nb, cxb_leb, ntile_cxb, nblk_cxb, lds_cxb, cxb_rec;
