@@ -310,6 +310,7 @@ int launch_eq_fwd_cxb(const Lay& l, const float* y, const float* ws, float* xhat
     // persistent workgroups: as many per CU as their LDS image (sample tile + kernel table) allows, at most four
     int per_cu = 160 * 1024 / (l.lds_eqcxb_fwd + 1024);
     per_cu = per_cu < 1 ? 1 : per_cu > 4 ? 4 : per_cu;
+    if (l.eqcxb_nbl >= 2 && per_cu > 2) per_cu = 2;   // register use allows two workgroups per CU from two lag blocks on
     if (nblk > CX_BLOCKS * per_cu) nblk = CX_BLOCKS * per_cu;
     int rc;
 #define V2VAE_LAUNCH_EQF(NBL)                                                                                     \

@@ -124,7 +124,11 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     }
     {
         int64_t nb = (l.sym_cnt + NT - 1) / NT;
-        l.nblk_sym = (int)(nb < 1024 ? nb : 1024);
+        // grid-stride kernels (soft demapper, per-symbol backward): as many workgroups as are resident at once - 256 CUs x
+        // the waves per SIMD their register use allows (3 up to 4 levels per stream, 2 up to 8, 1 beyond) - so that no second, partly
+        // filled round of workgroups trails the first
+        const int cap = 256 * (l.C <= 4 ? 3 : l.C <= 8 ? 2 : 1);
+        l.nblk_sym = (int)(nb < cap ? nb : cap);
     }
     // ---- matrix-core ELBO path: complex model, <= 16 active taps per stream and phase, S in {1, 2}
     l.use_cx = (l.mode == 1 && l.LE <= 16 && l.S <= 2 && getenv("V2VAE_FORCE_GENERIC") == nullptr) ? 1 : 0;
@@ -169,6 +173,10 @@ int make_layout(const v2vae_problem* p, Lay* out) {
         l.lds_eqcxb_bwd = (int)((a > b ? a : b) * 4);
     }
     if (l.use_eqcxb && l.lds_eqcxb_fwd > LDS_BUDGET) l.use_eqcxb = 0;
+    // persistent backward kernels: exactly the workgroups that are resident at once (register use: 3 per CU for the
+    // single-block kernel, 2 with two lag blocks, 1 with three), so that no partly filled second round trails the first
+    if (l.use_eqcx) l.nblk_eq = l.ntile_eq < 768 ? l.ntile_eq : 768;
+    if (l.use_eqcxb && l.eqcxb_nbl >= 3) l.nblk_eq = l.ntile_eq < 256 ? l.ntile_eq : 256;
     if (!generic_eq_ok && !l.use_eqcxb) return V2VAE_ESIZE;
     l.rec_elbo = l.S * rec_elbo_phase(l);
     l.rec_eq = l.ns * l.LT2p * l.LT2p + l.nk1;
@@ -507,14 +515,22 @@ __device__ __forceinline__ void d_demap_moments(const GridCtx gc, Lay l, const f
     for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int k = 0; k < CB; ++k) inv_pr[c][k] = (c < l.ns && k < l.C) ? 1.f / prior[c * l.C + k] : 0.f;
-    for (int64_t i = (int64_t)gc.bid * NT + threadIdx.x; i < l.sym_cnt; i += (int64_t)gc.nb * NT) {
+    const int64_t stride = (int64_t)gc.nb * NT;
+    float nx[2] = {0.f, 0.f};   // the next symbol's samples, requested one iteration ahead
+    {
+        const int64_t i0 = (int64_t)gc.bid * NT + threadIdx.x;
+        if (i0 < l.sym_cnt) { nx[0] = xhat[i0]; if (l.ns > 1) nx[1] = xhat[l.sym_cnt + i0]; }
+    }
+    for (int64_t i = (int64_t)gc.bid * NT + threadIdx.x; i < l.sym_cnt; i += stride) {
         const int64_t b = l.sym_lo + i;
         const bool in_kl = b >= l.kl_lo && b < l.kl_hi && b >= l.own_lo && b < l.own_lo + l.own_cnt;
+        const float cx[2] = {nx[0], nx[1]};
+        if (i + stride < l.sym_cnt) { nx[0] = xhat[i + stride]; if (l.ns > 1) nx[1] = xhat[l.sym_cnt + i + stride]; }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             if (c >= l.ns) break;
             Posterior p;
-            posterior<CB>(xhat[(int64_t)c * l.sym_cnt + i], levels + c * l.C, inv_den[c], l.C, p);
+            posterior<CB>(cx[c], levels + c * l.C, inv_den[c], l.C, p);
             float* m = mom + (int64_t)c * 4 * l.sym_cnt + i;
             m[0] = p.mu; m[l.sym_cnt] = p.var; m[2 * l.sym_cnt] = p.kap; m[3 * l.sym_cnt] = p.gam;
             float klb = 0.f;
@@ -592,21 +608,41 @@ __device__ __forceinline__ void d_sym_bwd(const GridCtx gc, Lay l, const float* 
             idn_f[c][k] = (float)inv_den[c][k];
             idn_sc[c][k] = in ? idn_f[c][k] / scaling[c * l.C + k] : 0.f;
         }
-    for (int64_t i = (int64_t)gc.bid * NT + threadIdx.x; i < l.sym_cnt; i += (int64_t)gc.nb * NT) {
+    // the loads of the next symbol are issued before the arithmetic of this one (the arithmetic is long enough to cover them)
+    float nx[2], ng[2][4];
+    auto fetch = [&](int64_t i) {
+        const int64_t b = l.sym_lo + i;
+        const bool own = i < l.sym_cnt && b >= l.own_lo && b < l.own_lo + l.own_cnt;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            nx[c] = 0.f; ng[c][0] = 0.f; ng[c][1] = 0.f; ng[c][2] = 0.f; ng[c][3] = 0.f;
+            if (own && c < l.ns) {
+                nx[c] = xhat[(int64_t)c * l.sym_cnt + i];
+                const float* g = gmom + (int64_t)c * 4 * l.sym_cnt + i;
+                ng[c][0] = g[0]; ng[c][1] = g[l.sym_cnt]; ng[c][2] = g[2 * l.sym_cnt]; ng[c][3] = g[3 * l.sym_cnt];
+            }
+        }
+    };
+    const int64_t stride = (int64_t)gc.nb * NT;
+    fetch((int64_t)gc.bid * NT + threadIdx.x);
+    for (int64_t i = (int64_t)gc.bid * NT + threadIdx.x; i < l.sym_cnt; i += stride) {
         const int64_t b = l.sym_lo + i;
         const bool own = b >= l.own_lo && b < l.own_lo + l.own_cnt;
         const bool in_kl = own && b >= l.kl_lo && b < l.kl_hi;
+        float cx[2], cg[2][4];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { cx[c] = nx[c]; cg[c][0] = ng[c][0]; cg[c][1] = ng[c][1]; cg[c][2] = ng[c][2]; cg[c][3] = ng[c][3]; }
+        fetch(i + stride);
 #pragma unroll
         for (int c = 0; c < 2; ++c)
             if (c < l.ns) {
                 float gx = 0.f;
                 if (own) {
-                    const float x = xhat[(int64_t)c * l.sym_cnt + i];
+                    const float x = cx[c];
                     const float* lv = levels + c * l.C;
                     Posterior p;
                     posterior<CB>(x, lv, inv_den[c], l.C, p);
-                    const float* g = gmom + (int64_t)c * 4 * l.sym_cnt + i;
-                    const float gmu = g[0], gv = g[l.sym_cnt], gk = g[2 * l.sym_cnt], gg = g[3 * l.sym_cnt];
+                    const float gmu = cg[c][0], gv = cg[c][1], gk = cg[c][2], gg = cg[c][3];
                     // Softmax backward in the pairwise form dz_k = q_k sum_j q_j (v_k - v_j): each term is a product of a
                     // (possibly tiny) probability with an O(1) difference, so nothing cancels against the posterior mean
                     // of v (which for peaked posteriors would be many orders above the result) and fp32 suffices.
