@@ -32,7 +32,7 @@ __device__ __forceinline__ void eqcx_load_tile(const Lay& l, const float* __rest
     }
 }
 
-__global__ __launch_bounds__(NT) void k_eq_bwd_cx(Lay l, const float* __restrict__ y, const float* __restrict__ gx,
+__global__ __launch_bounds__(NT, 4) void k_eq_bwd_cx(Lay l, const float* __restrict__ y, const float* __restrict__ gx,
                                                   float* __restrict__ ws) {
     extern __shared__ float sm[];
     float* tile = sm;

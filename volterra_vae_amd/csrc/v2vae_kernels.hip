@@ -125,10 +125,11 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     {
         int64_t nb = (l.sym_cnt + NT - 1) / NT;
         // grid-stride kernels (soft demapper, per-symbol backward): as many workgroups as are resident at once - 256 CUs x
-        // the waves per SIMD their register use allows (3 up to 4 levels per stream, 2 up to 8, 1 beyond) - so that no second, partly
-        // filled round of workgroups trails the first
-        const int cap = 256 * (l.C <= 4 ? 3 : l.C <= 8 ? 2 : 1);
+        // the waves per SIMD of their launch bounds - so that no second, partly filled round of workgroups trails the first
+        const int cap = 256 * (l.C <= 2 ? 4 : l.C <= 4 ? 3 : l.C <= 8 ? 2 : 1);
         l.nblk_sym = (int)(nb < cap ? nb : cap);
+        const int cap_dm = 256 * (l.C <= 4 ? 4 : l.C <= 8 ? 2 : 1);
+        l.nblk_dm = (int)(nb < cap_dm ? nb : cap_dm);
     }
     // ---- matrix-core ELBO path: complex model, <= 16 active taps per stream and phase, S in {1, 2}
     l.use_cx = (l.mode == 1 && l.LE <= 16 && l.S <= 2 && getenv("V2VAE_FORCE_GENERIC") == nullptr) ? 1 : 0;
@@ -173,9 +174,9 @@ int make_layout(const v2vae_problem* p, Lay* out) {
         l.lds_eqcxb_bwd = (int)((a > b ? a : b) * 4);
     }
     if (l.use_eqcxb && l.lds_eqcxb_fwd > LDS_BUDGET) l.use_eqcxb = 0;
-    // persistent backward kernels: exactly the workgroups that are resident at once (register use: 3 per CU for the
+    // persistent backward kernels: exactly the workgroups that are resident at once (register use: 4 per CU for the
     // single-block kernel, 2 with two lag blocks, 1 with three), so that no partly filled second round trails the first
-    if (l.use_eqcx) l.nblk_eq = l.ntile_eq < 768 ? l.ntile_eq : 768;
+    if (l.use_eqcx) l.nblk_eq = l.ntile_eq < 1024 ? l.ntile_eq : 1024;
     if (l.use_eqcxb && l.eqcxb_nbl >= 3) l.nblk_eq = l.ntile_eq < 256 ? l.ntile_eq : 256;
     if (!generic_eq_ok && !l.use_eqcxb) return V2VAE_ESIZE;
     l.rec_elbo = l.S * rec_elbo_phase(l);
@@ -233,7 +234,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
         if (l.nblk_cxb > nbE) nbE = l.nblk_cxb;
         l.o_Epart = take(2 * (int64_t)nbE);
     }
-    l.o_KLpart = take(2 * (int64_t)l.nblk_sym);
+    l.o_KLpart = take(2 * (int64_t)l.nblk_dm);
     l.total_floats = o;
     *out = l;
     return V2VAE_OK;
@@ -548,7 +549,7 @@ __device__ __forceinline__ void d_demap_moments(const GridCtx gc, Lay l, const f
 }
 
 template <int CB>
-__global__ __launch_bounds__(NT) void k_demap_moments(Lay l, const float* __restrict__ xhat, const float* __restrict__ levels,
+__global__ __launch_bounds__(NT, CB <= 4 ? 4 : CB <= 8 ? 2 : 1) void k_demap_moments(Lay l, const float* __restrict__ xhat, const float* __restrict__ levels,
                                                       const float* __restrict__ prior, const float* __restrict__ scaling,
                                                       const float* __restrict__ noise_var, float* __restrict__ ws,
                                                       float* __restrict__ q_out) {
@@ -697,7 +698,7 @@ __device__ __forceinline__ void d_sym_bwd(const GridCtx gc, Lay l, const float* 
 }
 
 template <int CB>
-__global__ __launch_bounds__(NT) void k_sym_bwd(Lay l, const float* __restrict__ xhat, const float* __restrict__ levels,
+__global__ __launch_bounds__(NT, CB <= 2 ? 4 : CB <= 4 ? 3 : CB <= 8 ? 2 : 1) void k_sym_bwd(Lay l, const float* __restrict__ xhat, const float* __restrict__ levels,
                                                 const float* __restrict__ prior, const float* __restrict__ scaling,
                                                 const float* __restrict__ noise_var, const double* __restrict__ scal,
                                                 const float* __restrict__ grad_scale, float* __restrict__ ws,
@@ -1158,7 +1159,7 @@ __device__ __forceinline__ void d_reduce_scalars(const GridCtx gc, Lay l, const 
     const double* Kp = reinterpret_cast<const double*>(ws + l.o_KLpart);
     double e = 0.0, k = 0.0;
     for (int i = threadIdx.x; i < l.nblk_E; i += NT) e += Ep[i];
-    for (int i = threadIdx.x; i < l.nblk_sym; i += NT) k += Kp[i];
+    for (int i = threadIdx.x; i < l.nblk_dm; i += NT) k += Kp[i];
     const double es = block_sum_double(e, red);
     const double ks = block_sum_double(k, red);
     if (threadIdx.x == 0) { scal[V2VAE_SCAL_E] = es; scal[V2VAE_SCAL_KL] = ks; }
@@ -1506,8 +1507,8 @@ __global__ __launch_bounds__(NT) void k_fit_persistent(Lay l, v2vae_fit_args a, 
             d_eq_fwd(GridCtx{t, nt_eqf}, l, yb, ws, xh);
             __syncthreads();
         }
-        for (int b = 0; b < l.nblk_sym; ++b) {
-            d_demap_moments<CB>(GridCtx{b, l.nblk_sym}, l, xh, a.levels, a.prior, sc, nv, ws, nullptr);
+        for (int b = 0; b < l.nblk_dm; ++b) {
+            d_demap_moments<CB>(GridCtx{b, l.nblk_dm}, l, xh, a.levels, a.prior, sc, nv, ws, nullptr);
             __syncthreads();
         }
         for (int b = 0; b < l.nblk_elbo; ++b) {
@@ -1648,7 +1649,7 @@ int v2vae_demap_moments(const v2vae_problem* p, const float* xhat, const float* 
     if (rc) return rc;
     if (!xhat || !levels || !prior || !scaling || !noise_var || !ws) return V2VAE_EINVAL;
 #define V2VAE_LAUNCH_DEMAP(CB)                                                                                     \
-    hipLaunchKernelGGL(k_demap_moments<CB>, dim3(l.nblk_sym), dim3(NT), 0, (hipStream_t)stream, l, xhat, levels, prior, \
+    hipLaunchKernelGGL(k_demap_moments<CB>, dim3(l.nblk_dm),  dim3(NT), 0, (hipStream_t)stream, l, xhat, levels, prior, \
                        scaling, noise_var, (float*)ws, q_out)
     if (l.C <= 2) V2VAE_LAUNCH_DEMAP(2);
     else if (l.C <= 4) V2VAE_LAUNCH_DEMAP(4);

@@ -50,7 +50,7 @@ struct Lay {
     // equaliser backward tiling
     int ntile_eq, nblk_eq, nitems_eq, nchunk_eq, maxi_eq, nk1;
     int lds_eq;              // bytes (forward and backward use the same carve)
-    int nblk_sym;
+    int nblk_sym, nblk_dm;   // workgroups of the per-symbol backward and of the soft demapper
     // matrix-core ELBO path
     int use_cx, ntile_cx, nblk_cx, lds_cx, nblk_E, nblk_psum;
     int64_t o_psum_part, o_psum_tot;
