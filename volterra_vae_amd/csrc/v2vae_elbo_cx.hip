@@ -42,7 +42,7 @@ constexpr int CX2_NSIG = 64;  // anti-diagonal entries kept per unit (47 used; 6
 
 template <int S, int NW>
 __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __restrict__ y, float* __restrict__ ws) {
-    extern __shared__ float sm[];
+    extern __shared__ __align__(16) float sm[];
     constexpr int TWB = CX2_TWB, MS = CX2_MS, TP = CX_TP, NU = CX2_NU, NSIG = CX2_NSIG;
     constexpr int NWP = NW / S;
     constexpr int CX2_NT = NW * 64;
@@ -54,19 +54,18 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
     float* s_A = s_stage + STG;           // [S][40][64]  A operands: steps 0-15 H X, 16-23 (H.H) s, 24-39 H w
     float* s_c = s_A + S * 40 * 64;           // [S][4][16]   h1r, h1i, diag Hr, diag Hi
     float* s_T = s_c + S * 64;                // [8 waves][32 * TP]  transposing buffer of rho / sigma
-    // anti-diagonal buffers, two per wave: 16 leading zeros, then 16 rows of 32 live + 16 zero entries (pitch 48), so
-    // that window index -15..47 of any row reads either data or zeros
-    constexpr int ADB = 16 + 16 * 48;
-    float* s_B = s_T + NW * 32 * TP;           // [NW waves][2][ADB]
-    float* s_P = s_B + NW * 2 * ADB;           // [S][NU][4][NSIG]
+    // anti-diagonal buffer, one per wave, of 4-vectors (the four gradient quantities of a (window, tap) pair travel
+    // together): 16 rows (taps) of 32 windows, then one zero vector that every out-of-range read is pointed at
+    constexpr int ADB = 16 * 32 + 4;           // vectors per wave
+    float* s_B = s_T + NW * 32 * TP;           // [NW waves][ADB][4]
+    float* s_P = s_B + NW * 4 * ADB;           // [S][NU][NSIG][4]
     __shared__ double dred[CX2_NT / 64];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int r = wv / NWP, wsub = wv % NWP;
     float* Tb = s_T + wv * 32 * TP;
-    float* Bd0 = s_B + wv * 2 * ADB + 16;
-    float* Bd1 = Bd0 + ADB;
+    f32x4* Bd = reinterpret_cast<f32x4*>(s_B) + wv * ADB;
     const float* __restrict__ mom = ws + l.o_mom;
     float* __restrict__ gmom = ws + l.o_gmom;
     const int64_t own_hi = l.own_lo + l.own_cnt, sym_hi = l.sym_lo + l.sym_cnt;
@@ -102,7 +101,7 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
         s_c[idx] = q == 0 ? ws[l.o_cxh1 + (rr * 2 + 0) * 16 + x] : q == 1 ? ws[l.o_cxh1 + (rr * 2 + 1) * 16 + x]
                  : q == 2 ? Hr[x * 16 + x] : Hi[x * 16 + x];
     }
-    for (int idx = tid; idx < NW * 2 * ADB; idx += CX2_NT) s_B[idx] = 0.f;
+    for (int idx = tid; idx < NW * 4 * ADB; idx += CX2_NT) s_B[idx] = 0.f;
     const float* Aop = s_A + (size_t)r * 40 * 64 + lane;
     // per-tap constants stay in LDS (all lanes of a half read one address: a broadcast, no bank conflict)
     const float* cst = s_c + r * 64 + 4 * h;
@@ -291,51 +290,36 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
                 HW = MFMA32(Aop[(24 + s) * 64], s < 8 ? al[(s & 7) >> 1][s & 1] : be[(s & 7) >> 1][s & 1], HW);
 #endif
 
-            // ---- anti-diagonal sums of the moment gradients, two quantities per round through the wave's buffer
             STAMP(3);
-            // ---- anti-diagonal sums of the moment gradients (symbol = window + tap), one quantity per round through
-            //      the wave's zero-padded buffer.  LDS instructions of one wave execute in program order, so lanes may
-            //      read what other lanes of the same wave wrote earlier; wave_barrier only pins the compiler's ordering.
-            float* Pu = s_P + ((size_t)(r * NU + sub) * 4) * NSIG;
+            // ---- anti-diagonal sums of the moment gradients (symbol = window + tap): the gradients of the two means and the
+            //      two variances of a (window, tap) pair go through the wave's zero-padded buffer as one 4-vector (the other
+            //      two pairs: k_g2_cx).  LDS instructions of one wave execute in program order, so lanes may read what other
+            //      lanes of the same wave wrote earlier; wave_barrier only pins the compiler's ordering.
+            f32x4* Pu = reinterpret_cast<f32x4*>(s_P) + (size_t)(r * NU + sub) * NSIG;
 #ifdef ABLATE_ANTIDIAG
 #pragma unroll
             for (int q = 0; q < 8; ++q) asm volatile("" ::"v"(HW[q]), "v"(HW[q + 8]), "v"(zz[q >> 1][q & 1]));
 #else
 #pragma unroll
-            for (int round = 0; round < 2; ++round) {   // gradients of the means, then of the variances (the other two: k_g2_cx)
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const int x = cx_kk(2 * p, h);
-                    const f2 zp = zP[p], zq = zQ[p], dr = C2(2, p), di = C2(3, p);
-                    f2 da, db;
-                    if (round == 0) {
-                        da = 2.f * (e0 * zp + e1 * zq + f2{HW[2 * p], HW[2 * p + 1]});
-                        db = 2.f * (e1 * zp - e0 * zq + f2{HW[2 * p + 8], HW[2 * p + 9]});
-                    } else {
-                        const f2 ed = 2.f * (e0 * dr + e1 * di);
-                        da = zz[p] + ed;
-                        db = zz[p] - ed;
-                    }
-                    da *= mv;
-                    db *= mv;
-                    Bd0[x * 48 + i] = da.x;
-                    Bd0[(x + 1) * 48 + i] = da.y;
-                    Bd1[x * 48 + i] = db.x;
-                    Bd1[(x + 1) * 48 + i] = db.y;
-                }
-                __builtin_amdgcn_wave_barrier();
-                if (lane < 48) {
-                    float sa = 0.f, sb = 0.f;
-#pragma unroll
-                    for (int x = 0; x < 16; ++x) {   // row x, window lane - x
-                        sa += Bd0[x * 47 + lane];
-                        sb += Bd1[x * 47 + lane];
-                    }
-                    Pu[(2 * round + 0) * NSIG + lane] = sa;
-                    Pu[(2 * round + 1) * NSIG + lane] = sb;
-                }
-                __builtin_amdgcn_wave_barrier();
+            for (int p = 0; p < 4; ++p) {
+                const int x = cx_kk(2 * p, h);
+                const f2 zp = zP[p], zq = zQ[p], dr = C2(2, p), di = C2(3, p);
+                const f2 ed = 2.f * (e0 * dr + e1 * di);
+                const f2 da0 = (2.f * mv) * (e0 * zp + e1 * zq + f2{HW[2 * p], HW[2 * p + 1]});
+                const f2 db0 = (2.f * mv) * (e1 * zp - e0 * zq + f2{HW[2 * p + 8], HW[2 * p + 9]});
+                const f2 da1 = mv * (zz[p] + ed), db1 = mv * (zz[p] - ed);
+                Bd[x * 32 + i] = f32x4{da0.x, db0.x, da1.x, db1.x};
+                Bd[(x + 1) * 32 + i] = f32x4{da0.y, db0.y, da1.y, db1.y};
             }
+            __builtin_amdgcn_wave_barrier();
+            {
+                f32x4 sv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int x = 0; x < 16; ++x)   // row x, window lane - x (the zero vector when that is not a window of the slab)
+                    sv += Bd[(unsigned)(lane - x) < 32u ? x * 31 + lane : 16 * 32];
+                Pu[lane] = sv;
+            }
+            __builtin_amdgcn_wave_barrier();
 #endif
 
             STAMP(4);
@@ -384,12 +368,12 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
                 float g0 = 0.f, g1 = 0.f;
                 for (int rr = 0; rr < S; ++rr) {
                     if (two) {
-                        const float* P = s_P + ((size_t)(rr * NU + sub_hi - 1) * 4) * NSIG + sg_hi + 32;
-                        g0 += P[(0 + c) * NSIG]; g1 += P[(2 + c) * NSIG];
+                        const float* P = s_P + ((size_t)(rr * NU + sub_hi - 1) * NSIG + sg_hi + 32) * 4;
+                        g0 += P[c]; g1 += P[2 + c];
                     }
                     if (sub_hi < NU) {
-                        const float* P = s_P + ((size_t)(rr * NU + sub_hi) * 4) * NSIG + sg_hi;
-                        g0 += P[(0 + c) * NSIG]; g1 += P[(2 + c) * NSIG];
+                        const float* P = s_P + ((size_t)(rr * NU + sub_hi) * NSIG + sg_hi) * 4;
+                        g0 += P[c]; g1 += P[2 + c];
                     }
                 }
                 float* gp = gmom + (int64_t)c * 4 * l.sym_cnt + (m - l.sym_lo);

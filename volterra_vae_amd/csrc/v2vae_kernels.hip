@@ -137,7 +137,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
         const int ts = 256 - l.kmax;
         l.ntile_cx = (int)((l.own_cnt + ts - 1) / ts);
         l.nblk_cx = l.ntile_cx < CX_BLOCKS ? l.ntile_cx : CX_BLOCKS;
-        l.lds_cx = ((7 * (256 + 48) + 2 * l.S * 256) + l.S * 40 * 64 + l.S * 64 + 8 * 32 * CX_TP + 8 * 2 * (16 + 16 * 48) + l.S * 8 * 4 * 64) * 4;
+        l.lds_cx = ((7 * (256 + 48) + 2 * l.S * 256) + l.S * 40 * 64 + l.S * 64 + 8 * 32 * CX_TP + 8 * 4 * (16 * 32 + 4) + l.S * 8 * 4 * 64) * 4;
         // blocked variant for longer channels
         l.use_cxb = (l.mode == 1 && l.LE > 16 && l.LE <= 48 && l.S <= 2 && getenv("V2VAE_FORCE_GENERIC") == nullptr) ? 1 : 0;
         l.cxb_nb = (l.LE + 15) / 16;
