@@ -358,26 +358,22 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
         __syncthreads();
         if (more) stage_store(s_stage);
         // ---- gather: symbol slot ms = kmax + ml is covered by subtile ms / 32 and, if ms % 32 <= Le - 2, by the one before
-        for (int idx = tid; idx < 2 * TS; idx += CX2_NT) {
-            const int c = idx / TS, ml = idx - c * TS;
+        //      (one thread per symbol: the 4-vector holds the gradients of both streams' means and variances)
+        for (int ml = tid; ml < TS; ml += CX2_NT) {
             const int64_t m = s0 + ml;
             if (m < s1) {
                 const int ms = ml + l.kmax;
                 const int sub_hi = ms >> 5, sg_hi = ms & 31;
                 const bool two = (sg_hi + 32 < 32 + l.LE - 1) && sub_hi > 0;
-                float g0 = 0.f, g1 = 0.f;
+                const f32x4* P4 = reinterpret_cast<const f32x4*>(s_P);
+                f32x4 g = {0.f, 0.f, 0.f, 0.f};
                 for (int rr = 0; rr < S; ++rr) {
-                    if (two) {
-                        const float* P = s_P + ((size_t)(rr * NU + sub_hi - 1) * NSIG + sg_hi + 32) * 4;
-                        g0 += P[c]; g1 += P[2 + c];
-                    }
-                    if (sub_hi < NU) {
-                        const float* P = s_P + ((size_t)(rr * NU + sub_hi) * NSIG + sg_hi) * 4;
-                        g0 += P[c]; g1 += P[2 + c];
-                    }
+                    if (two) g += P4[(rr * NU + sub_hi - 1) * NSIG + sg_hi + 32];
+                    if (sub_hi < NU) g += P4[(rr * NU + sub_hi) * NSIG + sg_hi];
                 }
-                float* gp = gmom + (int64_t)c * 4 * l.sym_cnt + (m - l.sym_lo);
-                gp[0] = g0; gp[l.sym_cnt] = g1;   // planes 2 and 3: k_g2_cx
+                float* gp = gmom + (m - l.sym_lo);   // planes 2 and 3 of either stream: k_g2_cx
+                const int64_t st = l.sym_cnt;
+                gp[0] = g.x; gp[st] = g.z; gp[4 * st] = g.y; gp[5 * st] = g.w;
             }
         }
         __syncthreads();
