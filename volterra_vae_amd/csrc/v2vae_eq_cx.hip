@@ -4,9 +4,10 @@
 // xhat_b = sum_j k1[j] y[bS + j - p1] + Y_b^T K Y_b,  K = k2 + k2^T complex symmetric, Y_b[x] = y[bS + p2 - x],
 // Y = Ya + j Yb.
 //
-// Backward: dK accumulates R += [rho | sigma]^T [Ya | Yb] over symbols with rho = g0 Ya + g1 Yb,
-// sigma = g1 Ya - g0 Yb (g = dloss/dxhat), four 32x32 tiles per wave, two symbols per k-step; a ones
-// column at index l2 of the Ya block yields the first-order gradient in the same product.
+// Backward: with rho = g0 Ya + g1 Yb, sigma = g1 Ya - g0 Yb (g = dloss/dxhat) the gradient planes are
+// dK_r = sum rho^T Ya + sigma^T Yb and dK_i = sum sigma^T Ya - rho^T Yb: two 32x32 accumulators per wave, two MFMAs into
+// each per k-step, two symbols per k-step; a ones column at index l2 of the Ya operand (zero in the Yb operand) yields
+// the first-order gradient in the same products.
 //
 // Applies when mode = complex, l2 odd <= 31, l1 odd <= l2 and pad1 = l1 / 2.
 #include <hip/hip_runtime.h>
@@ -39,9 +40,9 @@ __global__ __launch_bounds__(NT, 4) void k_eq_bwd_cx(Lay l, const float* __restr
     float* gt = tile + l.ns * l.tile_len;  // [2][EQ_TB]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
-    f32x16 R00, R01, R10, R11;
+    f32x16 Rr, Ri;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) { R00[g] = 0.f; R01[g] = 0.f; R10[g] = 0.f; R11[g] = 0.f; }
+    for (int g = 0; g < 16; ++g) { Rr[g] = 0.f; Ri[g] = 0.f; }
     const float* tr = tile;
     const float* ti = tile + l.tile_len;
     const bool ones_col = (j == l.l2);
@@ -65,32 +66,29 @@ __global__ __launch_bounds__(NT, 4) void k_eq_bwd_cx(Lay l, const float* __restr
             const float xa = tr[base], xb = ti[base];
             const float g0 = gt[bloc], g1 = gt[EQ_TB + bloc];
             const float rho = g0 * xa + g1 * xb, sig = g1 * xa - g0 * xb;
-            const float ca = ones_col ? 1.f : xa;
-            R00 = MFMA32(rho, ca, R00);
-            R01 = MFMA32(rho, xb, R01);
-            R10 = MFMA32(sig, ca, R10);
-            R11 = MFMA32(sig, xb, R11);
+            const float ca = ones_col ? 1.f : xa, cb = ones_col ? 0.f : xb;
+            Rr = MFMA32(rho, ca, Rr);
+            Ri = MFMA32(sig, ca, Ri);
+            Rr = MFMA32(sig, cb, Rr);
+            Ri = MFMA32(-rho, cb, Ri);
         }
     }
     // fixed-order reduction of the four waves through LDS, then one record per block
     __syncthreads();
-    float* img = sm;  // [4][1024]
+    float* img = sm;  // [2][1024]
     for (int w = 0; w < 4; ++w) {
         if (wv == w) {
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const int e = ((g & 3) + 8 * (g >> 2) + 4 * h) * 32 + j;
-                if (w == 0) {
-                    img[e] = R00[g]; img[1024 + e] = R01[g]; img[2048 + e] = R10[g]; img[3072 + e] = R11[g];
-                } else {
-                    img[e] += R00[g]; img[1024 + e] += R01[g]; img[2048 + e] += R10[g]; img[3072 + e] += R11[g];
-                }
+                if (w == 0) { img[e] = Rr[g]; img[1024 + e] = Ri[g]; }
+                else { img[e] += Rr[g]; img[1024 + e] += Ri[g]; }
             }
         }
         __syncthreads();
     }
-    float* rec = ws + l.o_part_eqcx + (size_t)blockIdx.x * 4096;
-    for (int e = tid; e < 4096; e += NT) rec[e] = img[e];
+    float* rec = ws + l.o_part_eqcx + (size_t)blockIdx.x * 2048;
+    for (int e = tid; e < 2048; e += NT) rec[e] = img[e];
 }
 
 __global__ __launch_bounds__(NT) void k_chain_equaliser_cx(Lay l, const float* __restrict__ ws, float* __restrict__ g_k1,
@@ -99,14 +97,14 @@ __global__ __launch_bounds__(NT) void k_chain_equaliser_cx(Lay l, const float* _
     const int l1 = l.l1, l2 = l.l2;
     const int n1 = 2 * l1, n2 = 2 * l2 * l2;
     auto GK = [&](int p, int a, int b) {  // dE/dK (effective symmetric kernel), plane p
-        return p == 0 ? T[0 * 1024 + a * 32 + b] + T[3 * 1024 + a * 32 + b] : T[2 * 1024 + a * 32 + b] - T[1 * 1024 + a * 32 + b];
+        return T[p * 1024 + a * 32 + b];
     };
     for (int idx = blockIdx.x * NT + threadIdx.x; idx < n1 + n2; idx += gridDim.x * NT) {
         if (idx < n1) {
             if (!g_k1) continue;
             const int p = idx / l1, jj = idx - p * l1;
             const int x = l.pad1 + l.p2 - jj;  // lag row that first-order tap jj multiplies
-            g_k1[idx] = T[(p == 0 ? 0 : 2) * 1024 + x * 32 + l2];
+            g_k1[idx] = T[p * 1024 + x * 32 + l2];
         } else {
             if (!g_k2) continue;
             const int e = idx - n1;

@@ -213,8 +213,8 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     l.o_cxbc = take(l.use_cxb ? (int64_t)l.S * 4 * l.cxb_leb : 0);
     l.o_part_cxb = take(l.use_cxb ? (int64_t)l.nblk_cxb * l.S * l.cxb_rec : 0);
     l.o_tot_cxb = take(l.use_cxb ? (int64_t)l.S * l.cxb_rec : 0);
-    l.o_part_eqcx = take(l.use_eqcx ? (int64_t)l.nblk_eq * 4096 : 0);
-    l.o_tot_eqcx = take(l.use_eqcx ? 4096 : 0);
+    l.o_part_eqcx = take(l.use_eqcx ? (int64_t)l.nblk_eq * 2048 : 0);
+    l.o_tot_eqcx = take(l.use_eqcx ? 2048 : 0);
     l.o_eqcxbA = take(l.eqcxb_fwd ? (int64_t)l.eqcx_steps * l.eqcxb_nbl * 128 + l.eqcxb_nbl * 64 : 0);
     l.o_part_eqcxb = take(l.use_eqcxb ? (int64_t)l.nblk_eq * l.eqcxb_rec : 0);
     l.o_tot_eqcxb = take(l.use_eqcxb ? l.eqcxb_rec : 0);
@@ -1775,7 +1775,7 @@ int v2vae_finish_grads(const v2vae_problem* p, void* ws, const double* scal, con
     else if ((which & 1) && l.use_cxb) sum_sets_add(ss, w + l.o_part_cxb, l.S * l.cxb_rec, l.nblk_cxb, stage, w + l.o_tot_cxb);
     else if (which & 1) sum_sets_add(ss, w + l.o_part_elbo, l.rec_elbo, l.nblk_elbo, stage, w + l.o_tot_elbo);
     if (which & 2) sum_sets_add(ss, w + l.o_part_sym, l.rec_sym, l.nblk_sym, stage + l.sumstage_stride, w + l.o_tot_sym);
-    if ((which & 4) && l.use_eqcx) sum_sets_add(ss, w + l.o_part_eqcx, 4096, l.nblk_eq, stage + 2 * l.sumstage_stride, w + l.o_tot_eqcx);
+    if ((which & 4) && l.use_eqcx) sum_sets_add(ss, w + l.o_part_eqcx, 2048, l.nblk_eq, stage + 2 * l.sumstage_stride, w + l.o_tot_eqcx);
     else if ((which & 4) && l.use_eqcxb) sum_sets_add(ss, w + l.o_part_eqcxb, l.eqcxb_rec, l.nblk_eq, stage + 2 * l.sumstage_stride, w + l.o_tot_eqcxb);
     else if (which & 4) sum_sets_add(ss, w + l.o_part_eq, l.rec_eq, l.nblk_eq, stage + 2 * l.sumstage_stride, w + l.o_tot_eq);
     sum_sets_launch(ss, st);
