@@ -31,13 +31,14 @@ def algorithmic_flops_per_symbol(L, S, l1, l2, cplx):
     multiply-adds per complex one.  ELBO per window on Le = L / S active taps, S windows per symbol:
       real     H mu, (H.H) v, H w (3 mat-vecs) + 3 rank-1 accumulations           = 12 Le^2 flops
       complex  H X and H w (complex mat-vecs, 8 Le^2 each), one complex rank-1 accumulation (8 Le^2),
-               (|H|^2) s (2 Le^2); the s s^T accumulation is O(Le) (lagged products)  = 26 Le^2 flops
+               = 24 Le^2 flops; the s s^T accumulation and the (|H|^2) s term of E with its gradient are O(Le) per
+               symbol (lagged products, correlations) and not counted
     i.e. only work the kernels actually execute is counted (the stacked real-valued formulation would be 48 Le^2)."""
     c = 4 if cplx else 1
     return {
         "eq_fwd": c * (2 * l1 + 2 * l2 * l2 + 2 * l2),
         "eq_bwd": c * (2 * l1 + 2 * l2 * l2),
-        "elbo_fused": (26 if cplx else 12) * L * L / S,
+        "elbo_fused": (24 if cplx else 12) * L * L / S,
     }
 
 

@@ -217,9 +217,9 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
             const bool own = valid && t >= s0;
             const float mv = valid ? 1.f : 0.f, mo = own ? 1.f : 0.f;
 
-            f32x16 U, TT;
+            f32x16 U;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) { U[g] = 0.f; TT[g] = 0.f; }
+            for (int g = 0; g < 16; ++g) U[g] = 0.f;
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int k = 2 * s + h;
@@ -230,11 +230,7 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
                 U = MFMA32(Aop[s * 64], b, U);
 #endif
             }
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const float b = s_S[tsl + i + 2 * s + h];
-                TT = MFMA32(Aop[(16 + s) * 64], b, TT);
-            }
+            // (no (H.H) s product: the term of E that holds it and its variance gradient come from k_g2_cx)
 
             STAMP(1);
             // per-tap algebra on tap PAIRS (2 p, 2 p + 1): their accumulator rows, moments and constants sit in neighbouring
@@ -244,7 +240,7 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const int slot = tsl + i + cx_kk(2 * p, h);
-                const f2 P = f2{U[2 * p], U[2 * p + 1]}, Q = f2{U[2 * p + 8], U[2 * p + 9]}, T = f2{TT[2 * p], TT[2 * p + 1]};
+                const f2 P = f2{U[2 * p], U[2 * p + 1]}, Q = f2{U[2 * p + 8], U[2 * p + 9]};
                 const f2 ma = ld2(s_mu + slot), mb = ld2(s_mu + MS + slot), Sv = ld2(s_S + slot), dv = ld2(s_dv + slot);
                 const f2 ka = ld2(s_ka + slot), kb = ld2(s_kb + slot), gs = ld2(s_gs + slot);
                 const f2 hr = C2(0, p), hi = C2(1, p), dr = C2(2, p), di = C2(3, p);
@@ -257,11 +253,11 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
                 sd1v += dv * di;
                 const f2 z2 = zp * zp + zq * zq;
                 const f2 ca = dr * zp + di * zq, cb = dr * zq - di * zp;
-                vsv += Sv * (z2 + 2.f * T) + 2.f * (ka * ca + kb * cb) + gs * (dr * dr + di * di);
+                vsv += Sv * z2 + 2.f * (ka * ca + kb * cb) + gs * (dr * dr + di * di);
                 al[p] = 2.f * (Sv * zp + ka * dr - kb * di);
                 be[p] = 2.f * (Sv * zq + ka * di + kb * dr);
                 zP[p] = zp; zQ[p] = zq;
-                zz[p] = z2 + 4.f * T;
+                zz[p] = z2;
                 dvv[p] = dv;
                 gdr[p] += (2.f * mo) * (ka * zp + kb * zq + gs * dr);
                 gdi[p] += (2.f * mo) * (ka * zq - kb * zp + gs * di);
@@ -373,7 +369,8 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
                 }
                 float* gp = gmom + (m - l.sym_lo);   // planes 2 and 3 of either stream: k_g2_cx
                 const int64_t st = l.sym_cnt;
-                gp[0] = g.x; gp[st] = g.z; gp[4 * st] = g.y; gp[5 * st] = g.w;
+                const float gT = ws[l.o_gT + (m - l.sym_lo)];   // the part of the variance gradient that k_g2_cx formed
+                gp[0] = g.x; gp[st] = g.z + gT; gp[4 * st] = g.y; gp[5 * st] = g.w + gT;
             }
         }
         __syncthreads();
@@ -480,63 +477,104 @@ __global__ __launch_bounds__(NT) void k_psum_cx(Lay l, float* __restrict__ ws) {
     }
 }
 
-// Gradient of E with respect to the 3rd central moments and the 4th cumulants of every owned symbol, right after the soft
-// demapper.  The former is LINEAR in the means with constant coefficients,
-//   g_a + i g_b at symbol m = 2 sum_{r,x} conj(d_x) z_{m-x,x},   z_{n,x} = h_x + 2 sum_j H_xj mu_{n+j}
-//                          = K0 + 4 sum_lag C[lag] mu_{m+lag},    C[lag] = sum_r sum_{j-x=lag} conj(d_x) H_xj,
-// a (2 Le - 1)-tap complex correlation per symbol, and the latter is the constant sum |d_x|^2 - for symbols all of whose
-// windows exist.  The few symbols at the two ends of the sequence take the explicit sums over the windows that do exist.
-// So the ELBO kernels only form the gradients with respect to means and variances (which need the residual).
+// What the backward needs of E that does not depend on the residual, right after the soft demapper:
+//  * the gradient with respect to the 3rd central moments is LINEAR in the means with constant coefficients,
+//      g_a + i g_b at symbol m = 2 sum_{r,x} conj(d_x) z_{m-x,x},   z_{n,x} = h_x + 2 sum_j H_xj mu_{n+j}
+//                             = K0 + 4 sum_lag C[lag] mu_{m+lag},    C[lag] = sum_r sum_{j-x=lag} conj(d_x) H_xj,
+//    a (2 Le - 1)-tap complex correlation per symbol; the gradient with respect to the 4th cumulants is the constant sum |d_x|^2;
+//  * the term 2 sum_n sum_x s_{n+x} T_{n,x}, T_{n,x} = sum_j |H_xj|^2 s_{n+j}, s = v_a + v_b, of E:
+//    its gradient with respect to either variance is the real correlation 4 sum_lag D[lag] s_{m+lag}, D[lag] = sum_r sum_x
+//    |H_{x,x+lag}|^2, written to a plane of its own (the ELBO kernel adds it to its part), and its value is
+//    2 sum_{r,x,j} |H_xj|^2 (sum_n s_{n+x} s_{n+j}) from the lagged products - one extra workgroup adds it to the partial sums
+//    of E - so the ELBO kernel forms no (H.H) s product at all.
+// All of this for symbols all of whose windows exist; the few symbols at the two ends of the sequence take the explicit
+// sums over the windows that do exist.
 constexpr int G2_TILE = 4 * NT;         // symbols per tile: four consecutive symbols per thread
 
 template <int NLAG>
 __global__ __launch_bounds__(NT) void k_g2_cx(Lay l, float* __restrict__ ws) {
-    constexpr int HALO = NLAG + 8;                     // staged means on either side of the tile
-    constexpr int PL = (G2_TILE + 2 * HALO) / 4;       // the staged means are kept as four planes by (index mod 4): a
+    constexpr int HALO = NLAG + 8;                     // staged symbols on either side of the tile
+    constexpr int PL = (G2_TILE + 2 * HALO) / 4;       // the staged values are kept as four planes by (index mod 4): a
                                                        // thread owns four consecutive symbols and every read is unit-stride
-    __shared__ float s_mq[2][4][PL];
+    __shared__ float s_mq[3][4][PL];                   // mean_a, mean_b, v_a + v_b
     __shared__ float s_cf[4 + 2 * (2 * NLAG + 8)];
-    __shared__ float s_e[NT / 64][3];
-    __shared__ float s_out[2][4][NT];                  // results, for coalesced stores
+    __shared__ float s_cd[2 * NLAG + 8];
+    __shared__ float s_e[NT / 64][4];
+    __shared__ double s_d[NT / 64];
+    __shared__ float s_out[3][4][NT];                  // results, for coalesced stores
     const float* __restrict__ mom = ws + l.o_mom;
     float* __restrict__ gmom = ws + l.o_gmom;
     const int64_t own_hi = l.own_lo + l.own_cnt, sym_hi = l.sym_lo + l.sym_cnt, st = l.sym_cnt;
     const int S = l.S;
     const int K4 = (l.kmax + 3) & ~3, ntap = 2 * K4 + 4;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int LE = l.LE, LTp = l.LTp;
+    const int nb = (int)gridDim.x - 1;                 // workgroups on symbols; the last one forms the value term
+
+    if ((int)blockIdx.x == nb) {
+        double v = 0.0;
+        for (int it = threadIdx.x; it < S * LE * LE; it += NT) {
+            const int r = it / (LE * LE), rem = it - r * LE * LE;
+            const int x = rem / LE, j = rem - x * LE;
+            const float hh = ws[l.o_HHc + ((size_t)(r * 2 + 0) * LTp + x) * LTp + j] + ws[l.o_HHc + ((size_t)(r * 2 + 1) * LTp + x) * LTp + j];
+            v += 2.0 * (double)hh * (double)psum_value(l, ws, r, x, j);
+        }
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) s_d[wv] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int w = 0; w < NT / 64; ++w) t += s_d[w];
+            reinterpret_cast<double*>(ws + l.o_Epart)[l.nblk_E - 1] = t;
+        }
+        return;
+    }
+
     for (int i = threadIdx.x; i < 4 + 2 * ntap; i += NT) s_cf[i] = ws[l.o_g2c + i];
+    for (int i = threadIdx.x; i < ntap; i += NT) s_cd[i] = ws[l.o_g2c + G2C_D + i];
     const int64_t ntile = (l.own_cnt + G2_TILE - 1) / G2_TILE;
-    for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    for (int64_t tile = blockIdx.x; tile < ntile; tile += nb) {
         const int64_t m0 = l.own_lo + tile * G2_TILE;
         __syncthreads();
         for (int e = threadIdx.x; e < G2_TILE + 2 * HALO; e += NT) {
             const int64_t m = m0 - HALO + e;
             const bool in = m >= l.sym_lo && m < sym_hi;
-            s_mq[0][e & 3][e >> 2] = in ? mom[m - l.sym_lo] : 0.f;
-            s_mq[1][e & 3][e >> 2] = in ? mom[4 * st + (m - l.sym_lo)] : 0.f;
+            const float* g = mom + (m - l.sym_lo);
+            s_mq[0][e & 3][e >> 2] = in ? g[0] : 0.f;
+            s_mq[1][e & 3][e >> 2] = in ? g[4 * st] : 0.f;
+            s_mq[2][e & 3][e >> 2] = in ? g[st] + g[5 * st] : 0.f;
         }
         __syncthreads();
-        // thread t owns symbols m0 + 4 t .. + 3; the window of means slides through registers
+        // thread t owns symbols m0 + 4 t .. + 3; the windows of means and of s slide through registers
         const int q0 = (HALO - K4) / 4 + threadIdx.x;    // first quad of the window (HALO and K4 are multiples of 4)
-        float wa[8], wb[8], ar[4], ai[4];
+        float wa[8], wb[8], wsv[8], ar[4], ai[4], at[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { wa[k] = s_mq[0][k][q0]; wb[k] = s_mq[1][k][q0]; ar[k] = 0.f; ai[k] = 0.f; }
+        for (int k = 0; k < 4; ++k) {
+            wa[k] = s_mq[0][k][q0]; wb[k] = s_mq[1][k][q0]; wsv[k] = s_mq[2][k][q0];
+            ar[k] = 0.f; ai[k] = 0.f; at[k] = 0.f;
+        }
         for (int g = 0; g < ntap / 4; ++g) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { wa[4 + k] = s_mq[0][k][q0 + g + 1]; wb[4 + k] = s_mq[1][k][q0 + g + 1]; }
+            for (int k = 0; k < 4; ++k) {
+                wa[4 + k] = s_mq[0][k][q0 + g + 1]; wb[4 + k] = s_mq[1][k][q0 + g + 1];
+                wsv[4 + k] = s_mq[2][k][q0 + g + 1];
+            }
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
                 const f2 cc = ld2(s_cf + 4 + 2 * (4 * g + tt));
+                const float cd = s_cd[4 * g + tt];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     ar[k] = fmaf(cc.x, wa[tt + k], ar[k]); ar[k] = fmaf(-cc.y, wb[tt + k], ar[k]);
                     ai[k] = fmaf(cc.x, wb[tt + k], ai[k]); ai[k] = fmaf(cc.y, wa[tt + k], ai[k]);
+                    at[k] = fmaf(cd, wsv[tt + k], at[k]);
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { wa[k] = wa[4 + k]; wb[k] = wb[4 + k]; }
+            for (int k = 0; k < 4; ++k) { wa[k] = wa[4 + k]; wb[k] = wb[4 + k]; wsv[k] = wsv[4 + k]; }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { s_out[0][k][threadIdx.x] = ar[k]; s_out[1][k][threadIdx.x] = ai[k]; }
+        for (int k = 0; k < 4; ++k) { s_out[0][k][threadIdx.x] = ar[k]; s_out[1][k][threadIdx.x] = ai[k]; s_out[2][k][threadIdx.x] = at[k]; }
         __syncthreads();
         const float k0r = s_cf[0], k0i = s_cf[1], g3c = s_cf[2];
         for (int i = threadIdx.x; i < G2_TILE; i += NT) {
@@ -548,23 +586,22 @@ __global__ __launch_bounds__(NT) void k_g2_cx(Lay l, float* __restrict__ ws) {
                 gp[6 * st] = fmaf(4.f, s_out[1][i & 3][i >> 2], k0i);
                 gp[3 * st] = g3c;
                 gp[7 * st] = g3c;
+                ws[l.o_gT + (m - l.sym_lo)] = 4.f * s_out[2][i & 3][i >> 2];
             }
         }
     }
 
     // ---- symbols at the ends of the sequence: m < kmax, or m >= W / S (some window (m - x) S + r does not exist); one
     //      workgroup per symbol, threads over (phase, tap, tap)
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t tail0 = l.W > 0 ? l.W / S : 0;
     const int64_t head_hi = own_hi < l.kmax ? own_hi : l.kmax;
     const int64_t nh = head_hi > l.own_lo ? head_hi - l.own_lo : 0;
     int64_t t0 = tail0 > l.kmax ? tail0 : l.kmax;
     if (t0 < l.own_lo) t0 = l.own_lo;
     const int64_t nt = own_hi > t0 ? own_hi - t0 : 0;
-    const int LE = l.LE, LTp = l.LTp;
-    for (int64_t e = blockIdx.x; e < nh + nt; e += gridDim.x) {
+    for (int64_t e = blockIdx.x; e < nh + nt; e += nb) {
         const int64_t m = e < nh ? l.own_lo + e : t0 + (e - nh);
-        float gr = 0.f, gi = 0.f, g3 = 0.f;
+        float gr = 0.f, gi = 0.f, g3 = 0.f, gt = 0.f;
         for (int it = threadIdx.x; it < S * LE * LE; it += NT) {
             const int r = it / (LE * LE), rem = it - r * LE * LE;
             const int x = rem / LE, j = rem - x * LE;
@@ -575,11 +612,15 @@ __global__ __launch_bounds__(NT) void k_g2_cx(Lay l, float* __restrict__ ws) {
             const float dr = Hr[x * LTp + x], di = Hi[x * LTp + x];
             const float hr = Hr[x * LTp + j], hi = Hi[x * LTp + j];
             const int64_t mm = m - x + j;
-            float ua = 0.f, ub = 0.f;
-            if (mm >= l.sym_lo && mm < sym_hi) { ua = mom[mm - l.sym_lo]; ub = mom[4 * st + (mm - l.sym_lo)]; }
+            float ua = 0.f, ub = 0.f, sv = 0.f;
+            if (mm >= l.sym_lo && mm < sym_hi) {
+                const float* g = mom + (mm - l.sym_lo);
+                ua = g[0]; ub = g[4 * st]; sv = g[st] + g[5 * st];
+            }
             const float cr = hr * ua - hi * ub, ci = hi * ua + hr * ub;
             gr += 4.f * (dr * cr + di * ci);
             gi += 4.f * (dr * ci - di * cr);
+            gt += 4.f * (hr * hr + hi * hi) * sv;
             if (j == 0) {
                 const float h1r = ws[l.o_h1c + (size_t)(r * 2 + 0) * LTp + x], h1i = ws[l.o_h1c + (size_t)(r * 2 + 1) * LTp + x];
                 gr += 2.f * (dr * h1r + di * h1i);
@@ -589,15 +630,17 @@ __global__ __launch_bounds__(NT) void k_g2_cx(Lay l, float* __restrict__ ws) {
         }
         for (int off = 32; off > 0; off >>= 1) {
             gr += __shfl_down(gr, off, 64); gi += __shfl_down(gi, off, 64); g3 += __shfl_down(g3, off, 64);
+            gt += __shfl_down(gt, off, 64);
         }
         __syncthreads();
-        if (lane == 0) { s_e[wv][0] = gr; s_e[wv][1] = gi; s_e[wv][2] = g3; }
+        if (lane == 0) { s_e[wv][0] = gr; s_e[wv][1] = gi; s_e[wv][2] = g3; s_e[wv][3] = gt; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            float a = 0.f, b = 0.f, c = 0.f;
-            for (int w = 0; w < NT / 64; ++w) { a += s_e[w][0]; b += s_e[w][1]; c += s_e[w][2]; }
+            float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+            for (int w = 0; w < NT / 64; ++w) { a += s_e[w][0]; b += s_e[w][1]; c += s_e[w][2]; d += s_e[w][3]; }
             float* gp = gmom + (m - l.sym_lo);
             gp[2 * st] = a; gp[6 * st] = b; gp[3 * st] = c; gp[7 * st] = c;
+            ws[l.o_gT + (m - l.sym_lo)] = d;
         }
     }
 }
@@ -688,11 +731,11 @@ void launch_psum_cx(const Lay& l, float* ws, hipStream_t st) {
     if (l.use_cxb) {
         hipLaunchKernelGGL(k_psum_cx<CX_MAXLAG>, dim3(l.nblk_psum), dim3(NT), 0, st, l, ws);
         hipLaunchKernelGGL(k_psum_finish_cx, dim3(1), dim3(NT), 0, st, l, ws, CX_MAXLAG);
-        hipLaunchKernelGGL(k_g2_cx<CX_MAXLAG>, dim3(ng), dim3(NT), 0, st, l, ws);
+        hipLaunchKernelGGL(k_g2_cx<CX_MAXLAG>, dim3(ng + 1), dim3(NT), 0, st, l, ws);
     } else {
         hipLaunchKernelGGL(k_psum_cx<16>, dim3(l.nblk_psum), dim3(NT), 0, st, l, ws);
         hipLaunchKernelGGL(k_psum_finish_cx, dim3(1), dim3(NT), 0, st, l, ws, 16);
-        hipLaunchKernelGGL(k_g2_cx<16>, dim3(ng), dim3(NT), 0, st, l, ws);
+        hipLaunchKernelGGL(k_g2_cx<16>, dim3(ng + 1), dim3(NT), 0, st, l, ws);   // + 1: the lagged-product term of E
     }
 }
 

@@ -236,14 +236,14 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
             float a0 = 0.f, a1 = 0.f, q0 = 0.f, q1 = 0.f, sd0 = 0.f, sd1 = 0.f, vs = 0.f;
             // the A operands of block pair p + 1 are requested before the MFMA chain of pair p is issued; sched_barrier keeps
             // the compiler from hoisting more than that one pair of loads (register budget)
-            float abuf[2][24];   // two register sets, alternating by block pair: no copies
+            float abuf[2][16];   // two register sets, alternating by block pair: no copies
 #pragma unroll
-            for (int s = 0; s < 24; ++s) abuf[0][s] = Abase[s * 64 + ulane];
+            for (int s = 0; s < 16; ++s) abuf[0][s] = Abase[s * 64 + ulane];
 #pragma unroll
             for (int xb = 0; xb < NB; ++xb) {
-                f32x16 U, TT;
+                f32x16 U;
 #pragma unroll
-                for (int g = 0; g < 16; ++g) { U[g] = 0.f; TT[g] = 0.f; }
+                for (int g = 0; g < 16; ++g) U[g] = 0.f;
 #pragma unroll
                 for (int jb = 0; jb < NB; ++jb) {
                     const int pr = xb * NB + jb;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                     if (pr + 1 < NB * NB) {
                         const gfloat_p A = Abase + (size_t)(pr + 1) * 40 * 64;
 #pragma unroll
-                        for (int s = 0; s < 24; ++s) abuf[(pr + 1) & 1][s] = A[s * 64 + ulane];
+                        for (int s = 0; s < 16; ++s) abuf[(pr + 1) & 1][s] = A[s * 64 + ulane];
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -259,15 +259,14 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                         const int k = 2 * s + h;
                         U = MFMA32(abuf[pr & 1][s], s_mu[(k >> 4) * MS + tsl + i + 16 * jb + (k & 15)], U);
                     }
-#pragma unroll
-                    for (int s = 0; s < 8; ++s) TT = MFMA32(abuf[pr & 1][16 + s], s_S[tsl + i + 16 * jb + 2 * s + h], TT);
+                    // (no (H.H) s product: the term of E that holds it and its variance gradient come from k_g2_cx)
                 }
                 BSTAMP(1);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int x = 16 * xb + cx_kk(q, h);
                     const int slot = tsl + i + x;
-                    const float P = U[q], Q = U[q + 8], T = TT[q];
+                    const float P = U[q], Q = U[q + 8];
                     const float4 m4a = s_m4[slot], m4b = s_m4[MS + slot];
                     const float ma = m4a.x, va = m4a.y, ka = m4a.z, ga = m4a.w;
                     const float mb = m4b.x, vb = m4b.y, kb = m4b.z, gb = m4b.w;
@@ -282,11 +281,11 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                     sd1 = fmaf(dv, di, sd1);
                     const float z2 = zp * zp + zq * zq;
                     const float ca = dr * zp + di * zq, cb = dr * zq - di * zp;
-                    vs += Sv * z2 + 2.f * Sv * T + 2.f * (ka * ca + kb * cb) + gs * (dr * dr + di * di);
+                    vs += Sv * z2 + 2.f * (ka * ca + kb * cb) + gs * (dr * dr + di * di);
                     al[xb][q] = 2.f * Sv * zp + 2.f * (ka * dr - kb * di);
                     be[xb][q] = 2.f * Sv * zq + 2.f * (ka * di + kb * dr);
                     zP[xb][q] = zp; zQ[xb][q] = zq;
-                    park_zz[(xb * 8 + q) * 64] = z2 + 4.f * T;
+                    park_zz[(xb * 8 + q) * 64] = z2;
                     park_dv[(xb * 8 + q) * 64] = dv;
                     gdr[xb][q] += mo * (2.f * (ka * zp + kb * zq) + 2.f * gs * dr);
                     gdi[xb][q] += mo * (2.f * (ka * zq - kb * zp) + 2.f * gs * di);
@@ -415,7 +414,7 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                     }
                 }
                 float* gp = gmom + (int64_t)c * 4 * l.sym_cnt + (m - l.sym_lo);
-                gp[0] = g0; gp[l.sym_cnt] = g1;   // planes 2 and 3: k_g2_cx
+                gp[0] = g0; gp[l.sym_cnt] = g1 + ws[l.o_gT + (m - l.sym_lo)];   // + the part k_g2_cx formed; planes 2 and 3: k_g2_cx
             }
         }
         __syncthreads();

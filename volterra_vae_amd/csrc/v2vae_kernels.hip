@@ -151,7 +151,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
             l.lds_cxb = ((11 * ms + 2 * l.S * CXB_TWB) + l.S * 4 * l.cxb_leb + 4 * 32 * CX_TP +
                          l.S * (CXB_TWB / 32) * 4 * nsig + l.S * l.cxb_rec + 4 * 2 * l.cxb_nb * 8 * 64) * 4;
         }
-        l.nblk_E = l.use_cx ? l.nblk_cx : (l.use_cxb ? l.nblk_cxb : l.nblk_elbo);
+        l.nblk_E = l.use_cx ? l.nblk_cx + 1 : (l.use_cxb ? l.nblk_cxb + 1 : l.nblk_elbo);   // + 1: the lagged-product term of E (k_g2_cx)
         if (!l.use_cx && !l.use_cxb && !generic_elbo_ok) return V2VAE_ESIZE;
         l.generic_elbo_ok = generic_elbo_ok;
         int64_t nb = (l.own_cnt + NT - 1) / NT;
@@ -207,7 +207,8 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     l.o_tot_cx = take((int64_t)l.S * CX_REC);
     l.o_psum_part = take(2 * CX_MAXLAG * (int64_t)l.nblk_psum);
     l.o_psum_tot = take(2 * CX_MAXLAG);
-    l.o_g2c = take((l.use_cx || l.use_cxb) ? 4 + 2 * (2 * CX_MAXLAG + 8) : 0);
+    l.o_g2c = take((l.use_cx || l.use_cxb) ? G2C_FLOATS : 0);
+    l.o_gT = take((l.use_cx || l.use_cxb) ? l.sym_cnt : 0);
     l.o_cxbA = take(l.use_cxb ? (int64_t)l.S * l.cxb_nb * l.cxb_nb * 40 * 64 : 0);
     l.o_cxbH = take(l.use_cxb ? (int64_t)l.S * 2 * l.cxb_leb * l.cxb_leb : 0);
     l.o_cxbc = take(l.use_cxb ? (int64_t)l.S * 4 * l.cxb_leb : 0);
@@ -232,7 +233,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     {
         int nbE = l.nblk_elbo > l.nblk_cx ? l.nblk_elbo : l.nblk_cx;
         if (l.nblk_cxb > nbE) nbE = l.nblk_cxb;
-        l.o_Epart = take(2 * (int64_t)nbE);
+        l.o_Epart = take(2 * (int64_t)(nbE + 1));
     }
     l.o_KLpart = take(2 * (int64_t)l.nblk_dm);
     l.total_floats = o;
@@ -359,11 +360,12 @@ __device__ __forceinline__ void d_prep_tables(const GridCtx gc, Lay l, const flo
     if ((l.use_cx || l.use_cxb) && h1) {
         // One wave per coefficient of the correlation form of the third-moment gradient (see k_g2_cx): with d the diagonal
         // of the symmetrised kernel H of phase r,  C[lag] = sum_r sum_x conj(d_x) H_{x, x + lag},  K0 = 2 sum conj(d_x) h_x,
-        // and the fourth-cumulant gradient of a symbol all of whose windows exist, sum |d_x|^2.
+        // the fourth-cumulant gradient of a symbol all of whose windows exist, sum |d_x|^2, and the coefficients of the part of
+        // the variance gradient that is a correlation of s = v_a + v_b,  D[lag] = sum_r sum_x |H_{x, x + lag}|^2.
         const int K4 = (l.kmax + 3) & ~3, ntap = 2 * K4 + 4;
         const int lane = threadIdx.x & 63;
         for (int c = tid >> 6; c <= ntap; c += nth >> 6) {
-            float cr = 0.f, ci = 0.f, g3 = 0.f;
+            float cr = 0.f, ci = 0.f, g3 = 0.f, dd = 0.f;
             for (int it = lane; it < l.S * l.LE; it += 64) {
                 const int r = it / l.LE, x = it - r * l.LE;
                 const int a = tap_index(l, r, x);
@@ -381,17 +383,19 @@ __device__ __forceinline__ void d_prep_tables(const GridCtx gc, Lay l, const flo
                     if (b < 0) continue;
                     ar = stacked_quad(l.mode, h2, l.L, 0, a, b);
                     ai = stacked_quad(l.mode, h2, l.L, 1, a, b);
+                    dd += ar * ar + ai * ai;
                 }
                 cr += dr * ar + di * ai;   // conj(d) * a
                 ci += dr * ai - di * ar;
             }
             for (int off = 32; off > 0; off >>= 1) {
                 cr += __shfl_down(cr, off, 64); ci += __shfl_down(ci, off, 64); g3 += __shfl_down(g3, off, 64);
+                dd += __shfl_down(dd, off, 64);
             }
             if (lane == 0) {
                 float* t = ws + l.o_g2c;
                 if (c == ntap) { t[0] = cr; t[1] = ci; t[2] = g3; t[3] = 0.f; }
-                else { t[4 + 2 * c] = cr; t[5 + 2 * c] = ci; }
+                else { t[4 + 2 * c] = cr; t[5 + 2 * c] = ci; t[G2C_D + c] = dd; }
             }
         }
     }

@@ -29,6 +29,8 @@ constexpr int SUM_CHUNKS = 32;       // first-stage groups of the two-stage part
 constexpr int CX_BLOCKS = 256;       // one workgroup per CU (the LDS image takes most of a CU)
 constexpr int CXB_TWB = 256;         // windows per phase per block tile of the blocked kernel
 constexpr int CX_MAXLAG = 48;        // lagged products kept for sum s s^T (largest blocked tap count)
+constexpr int G2C_D = 4 + 2 * (2 * CX_MAXLAG + 8);   // offset of the real coefficients D[lag] in the table at Lay::o_g2c
+constexpr int G2C_FLOATS = G2C_D + 2 * CX_MAXLAG + 8;
 
 struct Lay {
     int ns, mode, S, l1, pad1, l2, L, C;
@@ -55,8 +57,10 @@ struct Lay {
     int use_cx, ntile_cx, nblk_cx, lds_cx, nblk_E, nblk_psum;
     int64_t o_psum_part, o_psum_tot;
     // coefficients of the third-moment gradient as a correlation of the means (k_g2_cx): K0 (Re, Im), the constant
-    // fourth-cumulant gradient, 0, then (Re, Im) of C[lag] for lag = t - K4, t = 0 .. 2 K4 + 3, K4 = kmax rounded up to 4
+    // fourth-cumulant gradient, 0, then (Re, Im) of C[lag] for lag = t - K4, t = 0 .. 2 K4 + 3, K4 = kmax rounded up to 4;
+    // from G2C_D on the real D[lag] of the variance-gradient term that is a correlation of v_a + v_b
     int64_t o_g2c;
+    int64_t o_gT;   // [sym_cnt] the part of dE/dv (same for both streams) that is a correlation of v_a + v_b (matrix-core ELBO kernels)
     int64_t o_cxH, o_cxh1, o_part_cx, o_tot_cx;
     // blocked matrix-core ELBO path (complex, 16 < active taps per phase <= 48): taps in blocks of 16
     int use_cxb, cxb_nb, cxb_leb, ntile_cxb, nblk_cxb, lds_cxb, cxb_rec;
