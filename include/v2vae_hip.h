@@ -257,7 +257,10 @@ int v2vae_synth_channel(const v2vae_synth_args* a, float* y, int32_t* sym_idx, v
 uint64_t v2vae_synth_bits(uint64_t seed, uint64_t kind, uint64_t idx);
 
 /* Read-only views into the workspace for tests and tooling: float offsets (in floats from the
- * workspace base) of the per-symbol moments [ns][4][sym_cnt] and of dE/d(moments), same shape. */
+ * workspace base) of the per-symbol moments [ns][4][sym_cnt] and of dE/d(moments), same shape.
+ * When the complex model runs on the matrix-core ELBO kernels, plane 3 of dE/d(moments) (4th cumulant) is
+ * filled only for the symbols at the two ends of the sequence; for every other symbol the gradient is one
+ * constant that v2vae_sym_bwd takes from the coefficient table. */
 int64_t v2vae_ws_offset_moments(const v2vae_problem* p);
 int64_t v2vae_ws_offset_gmoments(const v2vae_problem* p);
 

@@ -576,7 +576,7 @@ __global__ __launch_bounds__(NT) void k_g2_cx(Lay l, float* __restrict__ ws) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) { s_out[0][k][threadIdx.x] = ar[k]; s_out[1][k][threadIdx.x] = ai[k]; s_out[2][k][threadIdx.x] = at[k]; }
         __syncthreads();
-        const float k0r = s_cf[0], k0i = s_cf[1], g3c = s_cf[2];
+        const float k0r = s_cf[0], k0i = s_cf[1];   // (the constant 4th-cumulant gradient s_cf[2] is read by k_sym_bwd directly)
         for (int i = threadIdx.x; i < G2_TILE; i += NT) {
             const int64_t m = m0 + i;
             // every window that holds this symbol exists: (m - kmax) * S >= 0 and m * S + S - 1 < W
@@ -584,8 +584,6 @@ __global__ __launch_bounds__(NT) void k_g2_cx(Lay l, float* __restrict__ ws) {
                 float* gp = gmom + (m - l.sym_lo);
                 gp[2 * st] = fmaf(4.f, s_out[0][i & 3][i >> 2], k0r);
                 gp[6 * st] = fmaf(4.f, s_out[1][i & 3][i >> 2], k0i);
-                gp[3 * st] = g3c;
-                gp[7 * st] = g3c;
                 ws[l.o_gT + (m - l.sym_lo)] = 4.f * s_out[2][i & 3][i >> 2];
             }
         }

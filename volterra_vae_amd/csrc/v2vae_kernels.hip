@@ -615,6 +615,8 @@ __device__ __forceinline__ void d_sym_bwd(const GridCtx gc, Lay l, const float* 
         }
     // the loads of the next symbol are issued before the arithmetic of this one (the arithmetic is long enough to cover them)
     float nx[2], ng[2][4];
+    const bool cx_path = l.use_cx || l.use_cxb;
+    const float g4c = cx_path ? ws[l.o_g2c + 2] : 0.f;
     auto fetch = [&](int64_t i) {
         const int64_t b = l.sym_lo + i;
         const bool own = i < l.sym_cnt && b >= l.own_lo && b < l.own_lo + l.own_cnt;
@@ -624,7 +626,10 @@ __device__ __forceinline__ void d_sym_bwd(const GridCtx gc, Lay l, const float* 
             if (own && c < l.ns) {
                 nx[c] = xhat[(int64_t)c * l.sym_cnt + i];
                 const float* g = gmom + (int64_t)c * 4 * l.sym_cnt + i;
-                ng[c][0] = g[0]; ng[c][1] = g[l.sym_cnt]; ng[c][2] = g[2 * l.sym_cnt]; ng[c][3] = g[3 * l.sym_cnt];
+                ng[c][0] = g[0]; ng[c][1] = g[l.sym_cnt]; ng[c][2] = g[2 * l.sym_cnt];
+                // matrix-core ELBO path: the 4th-cumulant gradient of a symbol all of whose windows exist is one constant
+                // (kept in the coefficient table); only the symbols at the ends of the sequence have it in the plane
+                ng[c][3] = (cx_path && b >= l.kmax && b * l.S + l.S - 1 < l.W) ? g4c : g[3 * l.sym_cnt];
             }
         }
     };
