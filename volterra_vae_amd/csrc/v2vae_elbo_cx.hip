@@ -693,9 +693,10 @@ __global__ __launch_bounds__(NT) void k_chain_channel_cx(Lay l, const float* __r
                 const float* tot = ws + l.o_tot_cx + (size_t)ri * CX_REC;
                 const float* Rm = tot;
                 const float* Hp = ws + l.o_cxH + (size_t)(ri * 2 + p) * 256;
+                const float ps = psum_value(l, ws, ri, xi, xj);   // symmetric in the tap pair
                 auto G = [&](int a, int b) {
                     float g = (p == 0) ? Rm[a * 32 + b] + Rm[(16 + a) * 32 + 16 + b] : Rm[(16 + a) * 32 + b] - Rm[a * 32 + 16 + b];
-                    g += 4.f * Hp[a * 16 + b] * psum_value(l, ws, ri, a, b);
+                    g += 4.f * Hp[a * 16 + b] * ps;
                     if (a == b) g += tot[2048 + (2 + p) * 16 + a];
                     return g;
                 };
