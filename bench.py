@@ -36,7 +36,8 @@ def algorithmic_flops_per_symbol(L, S, l1, l2, cplx):
     i.e. only work the kernels actually execute is counted (the stacked real-valued formulation would be 48 Le^2)."""
     c = 4 if cplx else 1
     return {
-        "eq_fwd": c * (2 * l1 + 2 * l2 * l2 + 2 * l2),
+        # complex, up to 31 lags: symmetric form, l2 (l2 + 1) / 2 + l2 complex multiply-adds (first-order kernel folded in)
+        "eq_fwd": 8 * (l2 * (l2 + 1) // 2 + l2) if (cplx and l2 <= 31) else c * (2 * l1 + 2 * l2 * l2 + 2 * l2),
         "eq_bwd": c * (2 * l1 + 2 * l2 * l2),
         "elbo_fused": (24 if cplx else 12) * L * L / S,
     }

@@ -20,6 +20,7 @@
 //
 // Applies when mode = complex, l2 odd <= 95, l1 odd <= l2 and pad1 = l1 / 2.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "v2vae_cx_common.h"
 #include "v2vae_layout.h"
@@ -67,6 +68,27 @@ __global__ __launch_bounds__(NT) void k_prep_eqcxb(Lay l, const float* __restric
         const int plane = idx / (NBL * 32), x = idx - plane * NBL * 32;
         const int jj = p1 + p2 - x;  // first-order tap that multiplies lag x
         ws[l.o_eqcxbA + n + idx] = (x < l2 && jj >= 0 && jj < l1) ? (plane == 0 ? k1r[jj] : k1i[jj]) : 0.f;
+    }
+    if (l.eqsym_t) {   // table of the symmetric-form forward kernel (k_eq_fwd_sym)
+        const int T = l.eqsym_t, np = T * (T + 1) / 2;
+        for (int idx = blockIdx.x * NT + threadIdx.x; idx < np + T; idx += gridDim.x * NT) {
+            float vr = 0.f, vi = 0.f;
+            if (idx < np) {
+                int a = 0, rem = idx;
+                while (rem >= T - a) { rem -= T - a; ++a; }
+                const int b = a + rem;
+                if (b < l2) {
+                    const float sc = a == b ? 1.f : 2.f;   // K_ab y_a y_b + K_ba y_b y_a
+                    vr = sc * (k2r[a * l2 + b] + k2r[b * l2 + a]);
+                    vi = sc * (k2i[a * l2 + b] + k2i[b * l2 + a]);
+                }
+            } else {
+                const int x = idx - np, jj = p1 + p2 - x;  // first-order tap that multiplies lag x
+                if (x < l2 && jj >= 0 && jj < l1) { vr = k1r[jj]; vi = k1i[jj]; }
+            }
+            ws[l.o_eqsym + 2 * idx] = vr;
+            ws[l.o_eqsym + 2 * idx + 1] = vi;
+        }
     }
 }
 
@@ -298,6 +320,72 @@ int launch_prep_eqcxb(const Lay& l, const float* k1, const float* k2, float* ws,
     return V2VAE_OK;
 }
 
+// Forward equaliser in symmetric form on the vector pipe, for kernels of up to 31 lags:
+//   xhat = sum_a y_a (k1w_a + sum_{b >= a} K'_ab y_b),  K'_ab = K_ab (a = b), 2 K_ab (a < b),  y_x = y[b S + p2 - x],
+// T (T + 1) / 2 + T complex multiply-adds per symbol instead of the T^2 of the matrix product (the f32 matrix rate equals the
+// packed vector rate on this part, so half the multiply-adds and no padding of the lag count to 32 is what counts).  One
+// symbol per thread: its T samples sit in registers, the kernel entries are wave-uniform (scalar loads), every multiply-add is
+// two packed FMAs.
+typedef float eq_f2 __attribute__((ext_vector_type(2)));
+
+template <int T>
+__global__ __launch_bounds__(NT, 4) void k_eq_fwd_sym(Lay l, const float* __restrict__ y, const float* __restrict__ ws,
+                                                      float* __restrict__ xhat) {
+    extern __shared__ float sm[];
+    float* tile = sm;
+    const int tid = threadIdx.x;
+    const float* __restrict__ tab = ws + l.o_eqsym;
+    constexpr int NP = T * (T + 1) / 2;
+    const int64_t sym_hi = l.sym_lo + l.sym_cnt;
+    const int64_t ntile = (l.sym_cnt + EQ_TB - 1) / EQ_TB;
+    for (int64_t t = blockIdx.x; t < ntile; t += gridDim.x) {
+        const int64_t b0 = l.sym_lo + t * EQ_TB;
+        __syncthreads();
+        {
+            const int64_t g0 = b0 * l.S - l.hl;
+            const int n = l.ns * l.tile_len;
+            for (int idx = tid; idx < n; idx += NT) {
+                const int c = idx >= l.tile_len ? 1 : 0, i = idx - c * l.tile_len;
+                const int64_t g = g0 + i;
+                float v = 0.f;
+                if (g >= 0 && g < l.n_glob) {
+                    const int64_t loc = g - l.y_lo;
+                    if (loc >= 0 && loc < l.y_len) v = y[(int64_t)c * l.y_stride + loc];
+                }
+                tile[idx] = v;
+            }
+        }
+        __syncthreads();
+        const int base = tid * l.S + l.hl + l.p2;
+        eq_f2 yv[T];
+#pragma unroll
+        for (int x = 0; x < T; ++x) {
+            const bool in = x < l.l2;
+            yv[x] = in ? eq_f2{tile[base - x], tile[l.tile_len + base - x]} : eq_f2{0.f, 0.f};
+        }
+        eq_f2 out = {0.f, 0.f};
+        int p = 0;
+#pragma unroll
+        for (int a = 0; a < T; ++a) {
+            const eq_f2 k1w = {tab[2 * (NP + a)], tab[2 * (NP + a) + 1]};
+            eq_f2 u = k1w;
+#pragma unroll
+            for (int b = a; b < T; ++b, ++p) {
+                const eq_f2 K = {tab[2 * p], tab[2 * p + 1]};
+                u += K.xx * yv[b];
+                u += eq_f2{-K.y, K.y} * yv[b].yx;
+            }
+            out += u.xx * yv[a];
+            out += eq_f2{-u.y, u.y} * yv[a].yx;
+        }
+        const int64_t b = b0 + tid;
+        if (b < sym_hi) {
+            xhat[b - l.sym_lo] = out.x;
+            xhat[l.sym_cnt + (b - l.sym_lo)] = out.y;
+        }
+    }
+}
+
 template <typename K>
 static int eqcxb_allow_lds(K kernel, int bytes) {
     if (bytes <= 64 * 1024) return V2VAE_OK;
@@ -307,6 +395,15 @@ static int eqcxb_allow_lds(K kernel, int bytes) {
 
 int launch_eq_fwd_cxb(const Lay& l, const float* y, const float* ws, float* xhat, hipStream_t st) {
     int nblk = (int)((l.sym_cnt + EQ_TB - 1) / EQ_TB);
+    if (l.eqsym_t && getenv("V2VAE_EQ_MFMA_FWD") == nullptr) {
+        const int nb = nblk < 4 * CX_BLOCKS ? nblk : 4 * CX_BLOCKS;   // four resident workgroups per CU (launch bounds)
+        const int lds = l.ns * l.tile_len * 4;
+        if (l.eqsym_t == 9) hipLaunchKernelGGL(k_eq_fwd_sym<9>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat);
+        else if (l.eqsym_t == 17) hipLaunchKernelGGL(k_eq_fwd_sym<17>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat);
+        else if (l.eqsym_t == 25) hipLaunchKernelGGL(k_eq_fwd_sym<25>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat);
+        else hipLaunchKernelGGL(k_eq_fwd_sym<31>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat);
+        return V2VAE_OK;
+    }
     // persistent workgroups: as many per CU as their LDS image (sample tile + kernel table) allows, at most four
     int per_cu = 160 * 1024 / (l.lds_eqcxb_fwd + 1024);
     per_cu = per_cu < 1 ? 1 : per_cu > 4 ? 4 : per_cu;

@@ -217,6 +217,8 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     l.o_part_eqcx = take(l.use_eqcx ? (int64_t)l.nblk_eq * 2048 : 0);
     l.o_tot_eqcx = take(l.use_eqcx ? 2048 : 0);
     l.o_eqcxbA = take(l.eqcxb_fwd ? (int64_t)l.eqcx_steps * l.eqcxb_nbl * 128 + l.eqcxb_nbl * 64 : 0);
+    l.eqsym_t = !l.use_eqcx ? 0 : l.l2 <= 9 ? 9 : l.l2 <= 17 ? 17 : l.l2 <= 25 ? 25 : 31;
+    l.o_eqsym = take(l.eqsym_t ? l.eqsym_t * (l.eqsym_t + 1) + 2 * l.eqsym_t : 0);
     l.o_part_eqcxb = take(l.use_eqcxb ? (int64_t)l.nblk_eq * l.eqcxb_rec : 0);
     l.o_tot_eqcxb = take(l.use_eqcxb ? l.eqcxb_rec : 0);
     {

@@ -71,6 +71,10 @@ struct Lay {
     // blocked matrix-core equaliser path (complex, 31 < l2 <= 95): lag rows in blocks of 32
     int use_eqcxb, eqcxb_fwd, eqcxb_nbl, eqcxb_rec, lds_eqcxb_fwd, lds_eqcxb_bwd;
     int64_t o_eqcxbA, o_part_eqcxb, o_tot_eqcxb;
+    // symmetric-form forward equaliser (complex, l2 <= 31): table of the upper-triangular kernel pairs, (Re, Im) each, off-diagonal
+    // entries doubled, rows a = 0 .. eqsym_t - 1 of columns b = a .. eqsym_t - 1, then the first-order kernel per lag (Re, Im)
+    int eqsym_t;             // compile-time lag count of the kernel instance that serves l2 (0: not used)
+    int64_t o_eqsym;
     int64_t o_sumstage;      // 3 x [SUM_CHUNKS][largest record] staging of the two-stage record sums (one per record set)
     int64_t sumstage_stride; // floats between the three staging areas
     // record sizes of the per-workgroup partial sums (floats)
