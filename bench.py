@@ -38,7 +38,8 @@ def algorithmic_flops_per_symbol(L, S, l1, l2, cplx):
     return {
         # complex, up to 31 lags: symmetric form, l2 (l2 + 1) / 2 + l2 complex multiply-adds (first-order kernel folded in)
         "eq_fwd": 8 * (l2 * (l2 + 1) // 2 + l2) if (cplx and l2 <= 31) else c * (2 * l1 + 2 * l2 * l2 + 2 * l2),
-        "eq_bwd": c * (2 * l1 + 2 * l2 * l2),
+        # the gradient planes are symmetric in the lag pair: the same count (the kernel accumulates 3 of 4 16x16 blocks)
+        "eq_bwd": 8 * (l2 * (l2 + 1) // 2 + l2) if (cplx and l2 <= 31) else c * (2 * l1 + 2 * l2 * l2),
         "elbo_fused": (24 if cplx else 12) * L * L / S,
     }
 

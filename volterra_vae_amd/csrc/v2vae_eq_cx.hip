@@ -5,8 +5,8 @@
 // Y = Ya + j Yb.
 //
 // Backward: with rho = g0 Ya + g1 Yb, sigma = g1 Ya - g0 Yb (g = dloss/dxhat) the gradient planes are
-// dK_r = sum rho^T Ya + sigma^T Yb and dK_i = sum sigma^T Ya - rho^T Yb: two 32x32 accumulators per wave, two MFMAs into
-// each per k-step, two symbols per k-step; a ones column at index l2 of the Ya operand (zero in the Yb operand) yields
+// dK_r = sum rho^T Ya + sigma^T Yb and dK_i = sum sigma^T Ya - rho^T Yb, both symmetric in the lag pair: the three
+// upper-triangular 16x16 blocks of each plane per wave, two 16x16x4 MFMAs into each per k-step, four symbols per k-step; a ones column at index l2 of the Ya operand (zero in the Yb operand) yields
 // the first-order gradient in the same products.
 //
 // Applies when mode = complex, l2 odd <= 31, l1 odd <= l2 and pad1 = l1 / 2.
@@ -16,8 +16,8 @@
 
 namespace v2vae {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 __device__ __forceinline__ void eqcx_load_tile(const Lay& l, const float* __restrict__ y, int64_t g0, float* tile) {
     const int n = l.ns * l.tile_len;
@@ -39,14 +39,17 @@ __global__ __launch_bounds__(NT, 4) void k_eq_bwd_cx(Lay l, const float* __restr
     float* tile = sm;
     float* gt = tile + l.ns * l.tile_len;  // [2][EQ_TB]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int j = lane & 31, h = lane >> 5;
-    f32x16 Rr, Ri;
+    const int i16 = lane & 15, kq = lane >> 4;
+    // Both gradient planes are symmetric in the lag pair, so of the 2 x 2 blocks of 16 lags only (0,0), (0,1), (1,1) are
+    // accumulated (16x16x4 MFMAs, four symbols per k-step); the chain rule reads block (1,0) from (0,1).
+    f32x4 Rr00, Rr01, Rr11, Ri00, Ri01, Ri11;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) { Rr[g] = 0.f; Ri[g] = 0.f; }
+    for (int g = 0; g < 4; ++g) { Rr00[g] = 0.f; Rr01[g] = 0.f; Rr11[g] = 0.f; Ri00[g] = 0.f; Ri01[g] = 0.f; Ri11[g] = 0.f; }
     const float* tr = tile;
     const float* ti = tile + l.tile_len;
-    const bool ones_col = (j == l.l2);
-    const int jc = j <= l.l2 ? j : l.l2;  // rows / columns beyond l2 are never read back; keep their loads in range
+    const int j0 = i16, j1 = 16 + i16;
+    const bool ones0 = (j0 == l.l2), ones1 = (j1 == l.l2);
+    const int jc0 = j0 <= l.l2 ? j0 : l.l2, jc1 = j1 <= l.l2 ? j1 : l.l2;  // rows / columns beyond l2 are never read back
     for (int t = blockIdx.x; t < l.ntile_eq; t += gridDim.x) {
         const int64_t b0 = l.own_lo + (int64_t)t * EQ_TB;
         const int64_t rem = l.own_lo + l.own_cnt - b0;
@@ -60,29 +63,36 @@ __global__ __launch_bounds__(NT, 4) void k_eq_bwd_cx(Lay l, const float* __restr
         __syncthreads();
         const int wbase = wv * 64;
 #pragma unroll 4
-        for (int s = 0; s < 32; ++s) {
-            const int bloc = wbase + 2 * s + h;
-            const int base = bloc * l.S + l.hl + l.p2 - jc;
-            const float xa = tr[base], xb = ti[base];
+        for (int s = 0; s < 16; ++s) {
+            const int bloc = wbase + 4 * s + kq;
+            const int base = bloc * l.S + l.hl + l.p2;
+            const float xa0 = tr[base - jc0], xb0 = ti[base - jc0], xa1 = tr[base - jc1], xb1 = ti[base - jc1];
             const float g0 = gt[bloc], g1 = gt[EQ_TB + bloc];
-            const float rho = g0 * xa + g1 * xb, sig = g1 * xa - g0 * xb;
-            const float ca = ones_col ? 1.f : xa, cb = ones_col ? 0.f : xb;
-            Rr = MFMA32(rho, ca, Rr);
-            Ri = MFMA32(sig, ca, Ri);
-            Rr = MFMA32(sig, cb, Rr);
-            Ri = MFMA32(-rho, cb, Ri);
+            const float rho0 = g0 * xa0 + g1 * xb0, sig0 = g1 * xa0 - g0 * xb0;
+            const float rho1 = g0 * xa1 + g1 * xb1, sig1 = g1 * xa1 - g0 * xb1;
+            const float ca0 = ones0 ? 1.f : xa0, cb0 = ones0 ? 0.f : xb0;
+            const float ca1 = ones1 ? 1.f : xa1, cb1 = ones1 ? 0.f : xb1;
+            Rr00 = MFMA16(rho0, ca0, Rr00); Ri00 = MFMA16(sig0, ca0, Ri00);
+            Rr01 = MFMA16(rho0, ca1, Rr01); Ri01 = MFMA16(sig0, ca1, Ri01);
+            Rr11 = MFMA16(rho1, ca1, Rr11); Ri11 = MFMA16(sig1, ca1, Ri11);
+            Rr00 = MFMA16(sig0, cb0, Rr00); Ri00 = MFMA16(-rho0, cb0, Ri00);
+            Rr01 = MFMA16(sig0, cb1, Rr01); Ri01 = MFMA16(-rho0, cb1, Ri01);
+            Rr11 = MFMA16(sig1, cb1, Rr11); Ri11 = MFMA16(-rho1, cb1, Ri11);
         }
     }
-    // fixed-order reduction of the four waves through LDS, then one record per block
+    // fixed-order reduction of the four waves through LDS, then one record per block: [2 planes][32][32], block (1,0) left zero
     __syncthreads();
     float* img = sm;  // [2][1024]
+    for (int e = tid; e < 2048; e += NT) img[e] = 0.f;
+    __syncthreads();
     for (int w = 0; w < 4; ++w) {
         if (wv == w) {
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int e = ((g & 3) + 8 * (g >> 2) + 4 * h) * 32 + j;
-                if (w == 0) { img[e] = Rr[g]; img[1024 + e] = Ri[g]; }
-                else { img[e] += Rr[g]; img[1024 + e] += Ri[g]; }
+            for (int g = 0; g < 4; ++g) {
+                const int a = 4 * kq + g, b = i16;
+                img[a * 32 + b] += Rr00[g];             img[1024 + a * 32 + b] += Ri00[g];
+                img[a * 32 + 16 + b] += Rr01[g];        img[1024 + a * 32 + 16 + b] += Ri01[g];
+                img[(16 + a) * 32 + 16 + b] += Rr11[g]; img[1024 + (16 + a) * 32 + 16 + b] += Ri11[g];
             }
         }
         __syncthreads();
@@ -97,7 +107,7 @@ __global__ __launch_bounds__(NT) void k_chain_equaliser_cx(Lay l, const float* _
     const int l1 = l.l1, l2 = l.l2;
     const int n1 = 2 * l1, n2 = 2 * l2 * l2;
     auto GK = [&](int p, int a, int b) {  // dE/dK (effective symmetric kernel), plane p
-        return T[p * 1024 + a * 32 + b];
+        return (a >= 16 && b < 16) ? T[p * 1024 + b * 32 + a] : T[p * 1024 + a * 32 + b];   // block (1,0) = (0,1) transposed
     };
     for (int idx = blockIdx.x * NT + threadIdx.x; idx < n1 + n2; idx += gridDim.x * NT) {
         if (idx < n1) {
