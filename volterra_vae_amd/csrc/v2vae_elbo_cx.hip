@@ -492,7 +492,7 @@ __global__ __launch_bounds__(NT) void k_psum_cx(Lay l, float* __restrict__ ws) {
 constexpr int G2_TILE = 4 * NT;         // symbols per tile: four consecutive symbols per thread
 
 template <int NLAG>
-__global__ __launch_bounds__(NT) void k_g2_cx(Lay l, float* __restrict__ ws) {
+__global__ __launch_bounds__(NT, 5) void k_g2_cx(Lay l, float* __restrict__ ws) {
     constexpr int HALO = NLAG + 8;                     // staged symbols on either side of the tile
     constexpr int PL = (G2_TILE + 2 * HALO) / 4;       // the staged values are kept as four planes by (index mod 4): a
                                                        // thread owns four consecutive symbols and every read is unit-stride
@@ -509,11 +509,14 @@ __global__ __launch_bounds__(NT) void k_g2_cx(Lay l, float* __restrict__ ws) {
     const int K4 = (l.kmax + 3) & ~3, ntap = 2 * K4 + 4;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int LE = l.LE, LTp = l.LTp;
-    const int nb = (int)gridDim.x - 1;                 // workgroups on symbols; the last one forms the value term
+    // the first G2_NE workgroups form the value term (first, so that their long chains of dependent loads start at once and
+    // overlap the symbol work instead of trailing it); the rest work on symbols
+    const int nb = (int)gridDim.x - G2_NE;
+    const int bid = (int)blockIdx.x - G2_NE;
 
-    if ((int)blockIdx.x == nb) {
+    if (bid < 0) {
         double v = 0.0;
-        for (int it = threadIdx.x; it < S * LE * LE; it += NT) {
+        for (int it = (int)blockIdx.x + G2_NE * (int)threadIdx.x; it < S * LE * LE; it += G2_NE * NT) {
             const int r = it / (LE * LE), rem = it - r * LE * LE;
             const int x = rem / LE, j = rem - x * LE;
             const float hh = ws[l.o_HHc + ((size_t)(r * 2 + 0) * LTp + x) * LTp + j] + ws[l.o_HHc + ((size_t)(r * 2 + 1) * LTp + x) * LTp + j];
@@ -525,7 +528,7 @@ __global__ __launch_bounds__(NT) void k_g2_cx(Lay l, float* __restrict__ ws) {
         if (threadIdx.x == 0) {
             double t = 0.0;
             for (int w = 0; w < NT / 64; ++w) t += s_d[w];
-            reinterpret_cast<double*>(ws + l.o_Epart)[l.nblk_E - 1] = t;
+            reinterpret_cast<double*>(ws + l.o_Epart)[l.nblk_E - G2_NE + (int)blockIdx.x] = t;
         }
         return;
     }
@@ -533,7 +536,7 @@ __global__ __launch_bounds__(NT) void k_g2_cx(Lay l, float* __restrict__ ws) {
     for (int i = threadIdx.x; i < 4 + 2 * ntap; i += NT) s_cf[i] = ws[l.o_g2c + i];
     for (int i = threadIdx.x; i < ntap; i += NT) s_cd[i] = ws[l.o_g2c + G2C_D + i];
     const int64_t ntile = (l.own_cnt + G2_TILE - 1) / G2_TILE;
-    for (int64_t tile = blockIdx.x; tile < ntile; tile += nb) {
+    for (int64_t tile = bid; tile < ntile; tile += nb) {
         const int64_t m0 = l.own_lo + tile * G2_TILE;
         __syncthreads();
         for (int e = threadIdx.x; e < G2_TILE + 2 * HALO; e += NT) {
@@ -597,7 +600,7 @@ __global__ __launch_bounds__(NT) void k_g2_cx(Lay l, float* __restrict__ ws) {
     int64_t t0 = tail0 > l.kmax ? tail0 : l.kmax;
     if (t0 < l.own_lo) t0 = l.own_lo;
     const int64_t nt = own_hi > t0 ? own_hi - t0 : 0;
-    for (int64_t e = blockIdx.x; e < nh + nt; e += nb) {
+    for (int64_t e = bid; e < nh + nt; e += nb) {
         const int64_t m = e < nh ? l.own_lo + e : t0 + (e - nh);
         float gr = 0.f, gi = 0.f, g3 = 0.f, gt = 0.f;
         for (int it = threadIdx.x; it < S * LE * LE; it += NT) {
@@ -730,11 +733,11 @@ void launch_psum_cx(const Lay& l, float* ws, hipStream_t st) {
     if (l.use_cxb) {
         hipLaunchKernelGGL(k_psum_cx<CX_MAXLAG>, dim3(l.nblk_psum), dim3(NT), 0, st, l, ws);
         hipLaunchKernelGGL(k_psum_finish_cx, dim3(1), dim3(NT), 0, st, l, ws, CX_MAXLAG);
-        hipLaunchKernelGGL(k_g2_cx<CX_MAXLAG>, dim3(ng + 1), dim3(NT), 0, st, l, ws);
+        hipLaunchKernelGGL(k_g2_cx<CX_MAXLAG>, dim3(ng + G2_NE), dim3(NT), 0, st, l, ws);
     } else {
         hipLaunchKernelGGL(k_psum_cx<16>, dim3(l.nblk_psum), dim3(NT), 0, st, l, ws);
         hipLaunchKernelGGL(k_psum_finish_cx, dim3(1), dim3(NT), 0, st, l, ws, 16);
-        hipLaunchKernelGGL(k_g2_cx<16>, dim3(ng + 1), dim3(NT), 0, st, l, ws);   // + 1: the lagged-product term of E
+        hipLaunchKernelGGL(k_g2_cx<16>, dim3(ng + G2_NE), dim3(NT), 0, st, l, ws);   // + G2_NE: the lagged-product term of E
     }
 }
 

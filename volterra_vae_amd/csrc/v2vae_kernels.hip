@@ -151,7 +151,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
             l.lds_cxb = ((11 * ms + 2 * l.S * CXB_TWB) + l.S * 4 * l.cxb_leb + 4 * 32 * CX_TP +
                          l.S * (CXB_TWB / 32) * 4 * nsig + l.S * l.cxb_rec + 4 * 2 * l.cxb_nb * 8 * 64) * 4;
         }
-        l.nblk_E = l.use_cx ? l.nblk_cx + 1 : (l.use_cxb ? l.nblk_cxb + 1 : l.nblk_elbo);   // + 1: the lagged-product term of E (k_g2_cx)
+        l.nblk_E = l.use_cx ? l.nblk_cx + G2_NE : (l.use_cxb ? l.nblk_cxb + G2_NE : l.nblk_elbo);   // + 1: the lagged-product term of E (k_g2_cx)
         if (!l.use_cx && !l.use_cxb && !generic_elbo_ok) return V2VAE_ESIZE;
         l.generic_elbo_ok = generic_elbo_ok;
         int64_t nb = (l.own_cnt + NT - 1) / NT;
@@ -235,7 +235,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     {
         int nbE = l.nblk_elbo > l.nblk_cx ? l.nblk_elbo : l.nblk_cx;
         if (l.nblk_cxb > nbE) nbE = l.nblk_cxb;
-        l.o_Epart = take(2 * (int64_t)(nbE + 1));
+        l.o_Epart = take(2 * (int64_t)(nbE + G2_NE));
     }
     l.o_KLpart = take(2 * (int64_t)l.nblk_dm);
     l.total_floats = o;

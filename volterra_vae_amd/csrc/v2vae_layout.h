@@ -31,6 +31,7 @@ constexpr int CXB_TWB = 256;         // windows per phase per block tile of the 
 constexpr int CX_MAXLAG = 48;        // lagged products kept for sum s s^T (largest blocked tap count)
 constexpr int G2C_D = 4 + 2 * (2 * CX_MAXLAG + 8);   // offset of the real coefficients D[lag] in the table at Lay::o_g2c
 constexpr int G2C_FLOATS = G2C_D + 2 * CX_MAXLAG + 8;
+constexpr int G2_NE = 8;   // workgroups of k_g2_cx that form the lagged-product term of E (one partial sum each)
 
 struct Lay {
     int ns, mode, S, l1, pad1, l2, L, C;
