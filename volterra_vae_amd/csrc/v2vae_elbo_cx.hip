@@ -520,7 +520,9 @@ __global__ __launch_bounds__(NT, 5) void k_g2_cx(Lay l, float* __restrict__ ws) 
             const int r = it / (LE * LE), rem = it - r * LE * LE;
             const int x = rem / LE, j = rem - x * LE;
             const float hh = ws[l.o_HHc + ((size_t)(r * 2 + 0) * LTp + x) * LTp + j] + ws[l.o_HHc + ((size_t)(r * 2 + 1) * LTp + x) * LTp + j];
-            v += 2.0 * (double)hh * (double)psum_value(l, ws, r, x, j);
+            const float ps = psum_value(l, ws, r, x, j);
+            ws[l.o_psv + it] = ps;   // kept for the chain rule of dE/dH
+            v += 2.0 * (double)hh * (double)ps;
         }
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
         if (lane == 0) s_d[wv] = v;
@@ -696,7 +698,7 @@ __global__ __launch_bounds__(NT) void k_chain_channel_cx(Lay l, const float* __r
                 const float* tot = ws + l.o_tot_cx + (size_t)ri * CX_REC;
                 const float* Rm = tot;
                 const float* Hp = ws + l.o_cxH + (size_t)(ri * 2 + p) * 256;
-                const float ps = psum_value(l, ws, ri, xi, xj);   // symmetric in the tap pair
+                const float ps = ws[l.o_psv + ((size_t)ri * l.LE + xi) * l.LE + xj];   // lagged sum of the tap pair (k_g2_cx)
                 auto G = [&](int a, int b) {
                     float g = (p == 0) ? Rm[a * 32 + b] + Rm[(16 + a) * 32 + 16 + b] : Rm[(16 + a) * 32 + b] - Rm[a * 32 + 16 + b];
                     g += 4.f * Hp[a * 16 + b] * ps;

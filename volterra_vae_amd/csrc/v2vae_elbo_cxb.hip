@@ -505,7 +505,7 @@ __global__ __launch_bounds__(NT) void k_chain_channel_cxb(Lay l, const float* __
             if (ri == rj) {
                 const float* tot = ws + l.o_tot_cxb + (size_t)ri * l.cxb_rec;
                 const float* Hp = ws + l.o_cxbH + (size_t)(ri * 2 + p) * LEB * LEB;
-                const float ps = psum_value(l, ws, ri, xi, xj);   // symmetric in the tap pair
+                const float ps = ws[l.o_psv + ((size_t)ri * l.LE + xi) * l.LE + xj];   // lagged sum of the tap pair (k_g2_cx)
                 auto G = [&](int a, int b) {
                     float g = tot[(p * LEB + a) * LEB + b] + 4.f * Hp[a * LEB + b] * ps;
                     if (a == b) g += tot[2 * LEB * LEB + (2 + p) * LEB + a];

@@ -209,6 +209,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     l.o_psum_tot = take(2 * CX_MAXLAG);
     l.o_g2c = take((l.use_cx || l.use_cxb) ? G2C_FLOATS : 0);
     l.o_gT = take((l.use_cx || l.use_cxb) ? l.sym_cnt : 0);
+    l.o_psv = take((l.use_cx || l.use_cxb) ? (int64_t)l.S * l.LE * l.LE : 0);
     l.o_cxbA = take(l.use_cxb ? (int64_t)l.S * l.cxb_nb * l.cxb_nb * 40 * 64 : 0);
     l.o_cxbH = take(l.use_cxb ? (int64_t)l.S * 2 * l.cxb_leb * l.cxb_leb : 0);
     l.o_cxbc = take(l.use_cxb ? (int64_t)l.S * 4 * l.cxb_leb : 0);

@@ -61,6 +61,7 @@ struct Lay {
     // fourth-cumulant gradient, 0, then (Re, Im) of C[lag] for lag = t - K4, t = 0 .. 2 K4 + 3, K4 = kmax rounded up to 4;
     // from G2C_D on the real D[lag] of the variance-gradient term that is a correlation of v_a + v_b
     int64_t o_g2c;
+    int64_t o_psv;  // [S][LE][LE] lagged sums of v_a + v_b per (phase, tap, tap) over the owned windows (k_g2_cx; read by the chain rule)
     int64_t o_gT;   // [sym_cnt] the part of dE/dv (same for both streams) that is a correlation of v_a + v_b (matrix-core ELBO kernels)
     int64_t o_cxH, o_cxh1, o_part_cx, o_tot_cx;
     // blocked matrix-core ELBO path (complex, 16 < active taps per phase <= 48): taps in blocks of 16
