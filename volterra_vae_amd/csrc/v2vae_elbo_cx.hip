@@ -46,6 +46,7 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
     constexpr int TWB = CX2_TWB, MS = CX2_MS, TP = CX_TP, NU = CX2_NU, NSIG = CX2_NSIG;
     constexpr int NWP = NW / S;
     constexpr int CX2_NT = NW * 64;
+    static_assert(CX2_TWB <= NW * 64, "the gather takes one thread per symbol of a tile");
     // one staging buffer of per-symbol planes [MS] each (unit stride: MFMA operands, and pairs of neighbouring taps load
     // as register pairs for packed arithmetic): mean_a, mean_b, v_a + v_b, v_a - v_b, 3rd central moments k_a, k_b,
     // sum of the 4th cumulants g_a + g_b; then y' [2][S][TWB]
@@ -208,6 +209,10 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
         const float* s_yw = s_stage + 7 * MS;
         const bool more = tile + (int)gridDim.x < l.ntile_cx;
         if (more) stage_load(tile + gridDim.x);
+        // the part of the variance gradient that k_g2_cx formed, for the symbol this thread gathers at the end of the tile:
+        // requested now, so that its latency is not paid between the two barriers of the gather
+        float gT_pre = 0.f;
+        if (tid < TS && s0 + tid < s1) gT_pre = ws[l.o_gT + (s0 + tid - l.sym_lo)];
         STAMP(0);
 
         for (int sub = wsub; sub < NU; sub += NWP) {
@@ -369,7 +374,7 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
                 }
                 float* gp = gmom + (m - l.sym_lo);   // planes 2 and 3 of either stream: k_g2_cx
                 const int64_t st = l.sym_cnt;
-                const float gT = ws[l.o_gT + (m - l.sym_lo)];   // the part of the variance gradient that k_g2_cx formed
+                const float gT = gT_pre;   // TS <= threads per workgroup: ml == tid
                 gp[0] = g.x; gp[st] = g.z + gT; gp[4 * st] = g.y; gp[5 * st] = g.w + gT;
             }
         }
