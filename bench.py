@@ -264,7 +264,8 @@ def main():
         "prep_tables": lambda: plan.prep_tables(h1, h2, k1, k2),
         "eq_fwd": lambda: plan.eq_fwd(y, xhat),
         "demap_moments": lambda: plan.demap_moments(xhat, levels, prior, sc, noise_var),
-        "elbo_fused": lambda: plan.elbo_fused(y),
+        "elbo_prepass": lambda: plan.elbo_prepass(),
+        "elbo_fused": lambda: plan.elbo_fused(y, prepass=False),
         "reduce_scalars": lambda: (plan.reduce_scalars(), plan.finalize_scalars()),
         "sym_bwd": lambda: plan.sym_bwd(xhat, levels, prior, sc, noise_var),
         "eq_bwd": lambda: plan.eq_bwd(y, plan.gxhat),

@@ -5,7 +5,8 @@
  * void*; NULL = the default stream), enqueues work asynchronously on that stream and returns
  * 0 on success or a negative V2VAE_E* code.  Nothing here allocates, frees or synchronises;
  * the caller owns every buffer, including the workspace (size from v2vae_workspace_bytes).
- * No global state: calls on different streams / devices with different workspaces are independent.
+ * Calls on different streams / devices with different workspaces are independent; the only process-wide state is the
+ * calling thread's last-error text and the per-kernel LDS-size attribute the launchers set.
  *
  * The reference has no FFI; the functions it exposes for this path are Python methods.  Each
  * entry point cites the reference code whose arithmetic it replaces (paths under the reference
@@ -43,6 +44,9 @@ extern "C" {
 #define V2VAE_ELAUNCH (-3)  /* HIP reported a launch error */
 #define V2VAE_ESIZE (-4)    /* problem too large for the kernels' on-chip tiling */
 
+#define V2VAE_FLAG_GENERIC 1     /* the generic FMA kernels for every shape (no matrix-core / on-chip kernels) */
+#define V2VAE_FLAG_EQ_MFMA_FWD 2 /* complex, l2 <= 31: the matrix-core forward equaliser instead of the symmetric-form one */
+
 typedef struct v2vae_problem {
     int32_t ns;      /* 1 or 2 */
     int32_t mode;    /* 0 real (bug-compatible with lib/real_equalization.py:869), 1 complex,
@@ -54,6 +58,9 @@ typedef struct v2vae_problem {
     int32_t l2;      /* second-order equaliser lags (odd) or 0 */
     int32_t L;       /* channel memory */
     int32_t C;       /* amplitude levels per stream (<= 16) */
+    int32_t flags;   /* 0, or V2VAE_FLAG_* bits: A/B switches for measurements between two HIP kernels of this library that
+                        cover the same shape.  Kernel dispatch and the workspace carve are functions of this struct alone. */
+    int32_t reserved; /* must be 0 */
     int64_t n_glob;  /* samples of the whole batch; zero padding applies outside [0, n_glob) */
     int64_t y_lo;    /* global sample index of y[.][0] */
     int64_t y_len;   /* samples per stream held locally */
@@ -90,13 +97,21 @@ int v2vae_prep_tables(const v2vae_problem* p, const float* h1, const float* h2, 
 int v2vae_eq_fwd(const v2vae_problem* p, const float* y, const void* ws, float* xhat, void* stream);
 
 /* Soft demapping + per-symbol posterior moments + KL partial sums
- * (lib/real_equalization.py:816-823, :847, :850-865).  q_out [ns][C][sym_cnt] may be NULL. */
+ * (lib/real_equalization.py:816-823, :847, :850-865).  q_out [ns][C][sym_cnt] may be NULL.  Needs no coefficient table:
+ * this alone (after v2vae_eq_fwd) is the inference path. */
 int v2vae_demap_moments(const v2vae_problem* p, const float* xhat, const float* levels,
                         const float* prior, const float* scaling, const float* noise_var, void* ws,
                         float* q_out, void* stream);
 
+/* The pieces of E and of dE/d(moments) that do not involve the residual y' - mean (terms of lib/real_equalization.py:887,
+ * :904-914 whose coefficients are constants of the channel kernels): lagged products of the posterior variances and per-symbol
+ * correlations.  Order: after v2vae_demap_moments AND v2vae_prep_tables(h1, h2), before v2vae_elbo_fused.  Launches nothing for
+ * shapes served by the generic ELBO kernel, which forms these terms itself. */
+int v2vae_elbo_prepass(const v2vae_problem* p, void* ws, void* stream);
+
 /* Closed-form ELBO expectations over sliding windows, forward and (unscaled) backward in one pass
- * (lib/real_equalization.py:868-918): partial sums of E, dE/d(channel kernels), dE/d(moments). */
+ * (lib/real_equalization.py:868-918): partial sums of E, dE/d(channel kernels), dE/d(moments).  Needs the moments of
+ * v2vae_demap_moments, the channel tables and the output of v2vae_elbo_prepass. */
 int v2vae_elbo_fused(const v2vae_problem* p, const float* y, void* ws, void* stream);
 
 /* Deterministic reduction of the E / KL partial sums of this rank into scal[E], scal[KL]. */

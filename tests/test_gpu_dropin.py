@@ -75,6 +75,47 @@ def test_fit_trajectory_matches_reference(case, capsys):
     assert abs(ser - float(g32["ser"])) <= 2.0 / len(g32["syms_val"])
 
 
+def test_refit_sequence_over_a_time_varying_channel_matches_reference(capsys):
+    """The change-point loop of the reference (main_time_varying_wh.py:121-149): fit() per chunk with carried optimiser
+    state, parameters and noise variance, lr_schedule=None, estimate_symbol_probs + SER after every chunk, the channel's
+    first FIR swapped between chunks.  Goldens from the reference (tests/golden/make_golden_refit.py)."""
+    from volterra_vae_amd.utility import calc_ser_from_probs
+    g32 = np.load(os.path.join(GOLDEN, "v2vae_real_refit_cfg3_f32.npz"))
+    g64 = np.load(os.path.join(GOLDEN, "v2vae_real_refit_cfg3_f64.npz"))
+    model = make_model(g32)
+    model.initialize_optimizer()
+    nb = int(g32["n_batches"])
+    for c in range(int(g32["n_chunks"])):
+        y_eq, loss = model.fit(g32[f"rx_{c}"])
+        assert len(loss) == nb
+
+        def chk(ours, key, tol):
+            r64, r32 = np.asarray(g64[key], dtype=np.float64), np.asarray(g32[key], dtype=np.float64)
+            own = np.linalg.norm(r32 - r64) / np.linalg.norm(r64)
+            e64, e32 = rel(ours, r64), rel(ours, r32)
+            print(f"chunk {c} {key}: vs fp64 ref {e64:.2e}, vs fp32 ref {e32:.2e} (ref32-ref64 {own:.2e})")
+            assert e64 < tol + own and e32 < tol + own, f"{key}: {e64:.2e} / {e32:.2e} (own {own:.2e})"
+
+        chk(loss, f"loss_{c}", 1e-5)
+        chk(y_eq, f"y_eq_{c}", 1e-5)
+        chk(model.channel_h1, f"h1_{c}", 1e-5)
+        chk(model.equaliser.kernel1, f"k1_{c}", 1e-5)
+        chk(model.noise_scaling, f"noise_scaling_{c}", 1e-5)
+        chk(model.channel_h2, f"h2_{c}", 1e-4)
+        chk(model.equaliser.kernel2, f"k2_{c}", 1e-4)
+        nv = float(g64[f"noise_variance_{c}"])
+        assert abs(float(model.noise_variance) - nv) < 1e-5 * nv
+        q = model.estimate_symbol_probs(g32[f"rx_val_{c}"])
+        assert rel(q, g32[f"q_val_{c}"]) < 1e-4
+        ser, delay = calc_ser_from_probs(q, g32[f"syms_val_{c}"], g32["constellation"])
+        assert delay == int(g32[f"ser_delay_{c}"])
+        assert abs(ser - float(g32[f"ser_{c}"])) <= 2.0 / len(g32[f"syms_val_{c}"])
+    # the optimiser's step count ran on across the fits (bias corrections of the third chunk use steps 41..60)
+    assert model.optimizer.step_count == int(g32["adam_step"]) == nb * int(g32["n_chunks"])
+    printed = capsys.readouterr().out
+    assert printed.count("Batch 0, Loss:") == int(g32["n_chunks"])
+
+
 def test_manual_step_api_equals_fused_fit():
     """forward -> _calculate_loss -> _update_model (autograd route) == the fused fit() step."""
     g = np.load(os.path.join(GOLDEN, "v2vae_real_fit_cfg1_f32.npz"))
@@ -98,6 +139,74 @@ def test_manual_step_api_equals_fused_fit():
         sched.step()
     assert rel(b._pack, a._pack.cpu().numpy()) < 1e-6
     assert abs(float(a.noise_variance) - float(b.noise_variance)) < 1e-6 * float(a.noise_variance)
+
+
+def _grads_of(model):
+    ps = [model.channel_h1, model.channel_h2, model.noise_scaling]
+    if hasattr(model, "equaliser"):
+        ps += [model.equaliser.kernel1, model.equaliser.kernel2]
+    else:
+        ps += [model.equaliser_k1, model.equaliser_k2]
+    out = [p.grad.detach().clone() for p in ps]
+    for p in ps:
+        p.grad = None
+    return out
+
+
+@pytest.mark.parametrize("cplx", [False, True], ids=["real", "complex"])
+def test_backward_survives_other_calls_on_the_same_plan(cplx):
+    """Autograd lets a caller run anything between a loss and its backward.  Inference on the same length and a second
+    loss before the first backward both reuse the model's plan (workspace); the gradients must not change."""
+    from volterra_vae_amd.synth import nonlinear_isi, pam_constellation, qam_constellation
+    rng = np.random.default_rng(9)
+    S, B = 2, 600
+    if cplx:
+        from volterra_vae_amd.complex_equalization import SecondVolterraV2VAE
+        const = qam_constellation(16)
+        model = SecondVolterraV2VAE(channel_memory=25, learning_rate=5e-3, constellation=const, samples_per_symbol=S, batch_size=B,
+                                    noise_variance=0.05, torch_device=torch.device("cuda"), equaliser_n_lags1=25,
+                                    equaliser_n_lags2=25)
+        rx, _ = nonlinear_isi(2 * B, const, S, 16.0, rng)
+        y = torch.from_numpy(model.to_real_stacked(rx)).float().cuda()
+    else:
+        from volterra_vae_amd.real_equalization import SecondVolterraV2VAE
+        const = pam_constellation(4)
+        model = SecondVolterraV2VAE(channel_memory=15, equaliser_n_lags1=25, equaliser_n_lags2=25, learning_rate=5e-3,
+                                    constellation=const, batch_size=B, samples_per_symbol=S, noise_variance=0.05,
+                                    torch_device=torch.device("cuda"))
+        rx, _ = nonlinear_isi(2 * B, const, S, 16.0, rng)
+        y = torch.from_numpy(rx).float().cuda()
+    model.adaptive_noise_variance = False   # keep sigma^2 fixed so that the three runs see identical inputs
+    with torch.no_grad():
+        model.channel_h2 += 0.02 * torch.randn_like(model.channel_h2)
+    ya, yb = y[..., :B * S].contiguous(), y[..., B * S:].contiguous()
+
+    def loss_of(ysl):
+        return model._calculate_loss(model.forward(ysl), ysl)
+
+    loss_of(ya).backward()
+    ga = _grads_of(model)
+    loss_of(yb).backward()
+    gb = _grads_of(model)
+    # (1) inference of the same length between loss and backward
+    la = loss_of(ya)
+    with torch.no_grad():
+        model.forward_probs(yb)
+    la.backward()
+    for g, r in zip(_grads_of(model), ga):
+        assert torch.equal(g, r)
+    # (2) two losses, then both backwards (the first one's forward state has been overwritten by the second)
+    la, lb = loss_of(ya), loss_of(yb)
+    la.backward()
+    g1 = _grads_of(model)
+    lb.backward()
+    g2 = _grads_of(model)
+    for g, r in zip(g1 + g2, ga + gb):
+        assert torch.equal(g, r)
+    # (3) gradient accumulation: one backward of the sum
+    (loss_of(ya) + loss_of(yb)).backward()
+    for g, ra, rb in zip(_grads_of(model), ga, gb):
+        assert rel(g, (ra + rb).cpu().numpy()) < 1e-6
 
 
 def test_long_fit_ser_matches_reference():

@@ -24,7 +24,8 @@ lv = torch.arange(-(M - 1), M, 2, dtype=torch.float32, device="cuda"); levels = 
 prior = torch.full_like(levels, 1.0 / M); nv = torch.tensor([0.03], device="cuda")
 xhat = torch.empty((2, B), device="cuda")
 plan.prep_tables(h1, h2, k1, k2); plan.eq_fwd(y, xhat); plan.demap_moments(xhat, levels, prior, sc, nv)
-for _ in range(2): plan.elbo_fused(y)
+plan.elbo_prepass()
+for _ in range(2): plan.elbo_fused(y, prepass=False)
 torch.cuda.synchronize()
 off = ctypes.CDLL(None)  # dummy
 # locate o_sumstage via a second plan-less trick: the debug area is at ws + o_sumstage; find by scanning is hard -> expose through env

@@ -47,7 +47,8 @@ stages = {
     "prep_tables": lambda: plan.prep_tables(h1, h2, k1, k2 if a.l2 else None),
     "eq_fwd": lambda: plan.eq_fwd(y, xhat),
     "demap_moments": lambda: plan.demap_moments(xhat, levels, prior, sc, nv),
-    "elbo_fused": lambda: plan.elbo_fused(y),
+    "elbo_prepass": lambda: plan.elbo_prepass(),
+    "elbo_fused": lambda: plan.elbo_fused(y, prepass=False),
     "reduce_scalars": lambda: (plan.reduce_scalars(), plan.finalize_scalars()),
     "sym_bwd": lambda: plan.sym_bwd(xhat, levels, prior, sc, nv),
     "eq_bwd": lambda: plan.eq_bwd(y, plan.gxhat),

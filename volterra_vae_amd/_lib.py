@@ -21,12 +21,24 @@ OK, EINVAL, EHALO, ELAUNCH, ESIZE = 0, -1, -2, -3, -4
 _ERR = {EINVAL: "invalid argument / unsupported shape", EHALO: "local sample or symbol range does not cover the halo",
         ELAUNCH: "HIP launch error", ESIZE: "problem exceeds the kernels' on-chip tiling limits"}
 
+FLAG_GENERIC, FLAG_EQ_MFMA_FWD = 1, 2
+
+
+def default_flags() -> int:
+    """Kernel A/B switches for measurements and tooling, taken from the environment when a problem is set up
+    (V2VAE_FORCE_GENERIC: generic FMA kernels everywhere; V2VAE_EQ_MFMA_FWD: matrix-core forward equaliser).  The
+    library itself never reads the environment: the choice travels in `Problem.flags`."""
+    return (FLAG_GENERIC if os.environ.get("V2VAE_FORCE_GENERIC") else 0) | \
+        (FLAG_EQ_MFMA_FWD if os.environ.get("V2VAE_EQ_MFMA_FWD") else 0)
+
+
 SCAL_E, SCAL_KL, SCAL_LOSS, SCAL_LAMBDA, SCAL_W, SCAL_COUNT = 0, 1, 2, 3, 4, 8
 
 
 class Problem(C.Structure):
     _fields_ = [("ns", C.c_int32), ("mode", C.c_int32), ("sps", C.c_int32), ("l1", C.c_int32),
                 ("pad1", C.c_int32), ("l2", C.c_int32), ("L", C.c_int32), ("C", C.c_int32),
+                ("flags", C.c_int32), ("reserved", C.c_int32),
                 ("n_glob", C.c_int64), ("y_lo", C.c_int64), ("y_len", C.c_int64),
                 ("sym_lo", C.c_int64), ("sym_cnt", C.c_int64), ("own_lo", C.c_int64), ("own_cnt", C.c_int64)]
 
@@ -72,6 +84,7 @@ EXPORTS = {
     "v2vae_prep_tables": (C.c_int, [C.POINTER(Problem)] + [C.c_void_p] * 6),
     "v2vae_eq_fwd": (C.c_int, [C.POINTER(Problem)] + [C.c_void_p] * 4),
     "v2vae_demap_moments": (C.c_int, [C.POINTER(Problem)] + [C.c_void_p] * 8),
+    "v2vae_elbo_prepass": (C.c_int, [C.POINTER(Problem)] + [C.c_void_p] * 2),
     "v2vae_elbo_fused": (C.c_int, [C.POINTER(Problem)] + [C.c_void_p] * 3),
     "v2vae_reduce_scalars": (C.c_int, [C.POINTER(Problem)] + [C.c_void_p] * 3),
     "v2vae_finalize_scalars": (C.c_int, [C.POINTER(Problem)] + [C.c_void_p] * 2),

@@ -395,7 +395,7 @@ static int eqcxb_allow_lds(K kernel, int bytes) {
 
 int launch_eq_fwd_cxb(const Lay& l, const float* y, const float* ws, float* xhat, hipStream_t st) {
     int nblk = (int)((l.sym_cnt + EQ_TB - 1) / EQ_TB);
-    if (l.eqsym_t && getenv("V2VAE_EQ_MFMA_FWD") == nullptr) {
+    if (l.eqsym_t && !(l.flags & V2VAE_FLAG_EQ_MFMA_FWD)) {
         const int nb = nblk < 4 * CX_BLOCKS ? nblk : 4 * CX_BLOCKS;   // four resident workgroups per CU (launch bounds)
         const int lds = l.ns * l.tile_len * 4;
         if (l.eqsym_t == 9) hipLaunchKernelGGL(k_eq_fwd_sym<9>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat);

@@ -47,7 +47,7 @@ static inline int rs_rup(int x, int m) { return (x + m - 1) / m * m; }
 
 // Fills `o` and returns 1 if the shape fits this kernel.
 int rs_plan(const Lay& l, int64_t pack, RsOff* o) {
-    if (getenv("V2VAE_FORCE_GENERIC")) return 0;
+    if (l.flags & V2VAE_FLAG_GENERIC) return 0;
     if (l.mode != 0 || l.ns != 1 || l.LE > 8 || l.S > 4 || l.l2 > 31 || l.l1 > 64 || l.pad1 > RS_HL || l.C > MAX_C) return 0;
     if (pack > RS_APT * RS_NT || l.b_glob > 4096 || l.n_glob > 8192) return 0;
     const int B = (int)l.b_glob, N = (int)l.n_glob;

@@ -23,6 +23,8 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     if (!p || !out) return V2VAE_EINVAL;
     Lay l{};
     l.ns = p->ns; l.S = p->sps;
+    if (p->flags & ~(V2VAE_FLAG_GENERIC | V2VAE_FLAG_EQ_MFMA_FWD) || p->reserved != 0) return V2VAE_EINVAL;
+    l.flags = p->flags;
     if (p->mode < 0 || p->mode > 3) return V2VAE_EINVAL;
     l.chan = p->mode >= 2 ? p->mode - 1 : 0;  // modes 2, 3: real path with a polynomial channel model
     l.mode = p->mode >= 2 ? 0 : p->mode; l.l1 = p->l1; l.pad1 = p->pad1; l.l2 = p->l2;
@@ -132,14 +134,14 @@ int make_layout(const v2vae_problem* p, Lay* out) {
         l.nblk_dm = (int)(nb < cap_dm ? nb : cap_dm);
     }
     // ---- matrix-core ELBO path: complex model, <= 16 active taps per stream and phase, S in {1, 2}
-    l.use_cx = (l.mode == 1 && l.LE <= 16 && l.S <= 2 && getenv("V2VAE_FORCE_GENERIC") == nullptr) ? 1 : 0;
+    l.use_cx = (l.mode == 1 && l.LE <= 16 && l.S <= 2 && !(l.flags & V2VAE_FLAG_GENERIC)) ? 1 : 0;
     {
         const int ts = 256 - l.kmax;
         l.ntile_cx = (int)((l.own_cnt + ts - 1) / ts);
         l.nblk_cx = l.ntile_cx < CX_BLOCKS ? l.ntile_cx : CX_BLOCKS;
         l.lds_cx = ((7 * (256 + 48) + 2 * l.S * 256) + l.S * 40 * 64 + l.S * 64 + 8 * 32 * CX_TP + 8 * 4 * (16 * 32 + 4) + l.S * 8 * 4 * 64) * 4;
         // blocked variant for longer channels
-        l.use_cxb = (l.mode == 1 && l.LE > 16 && l.LE <= 48 && l.S <= 2 && getenv("V2VAE_FORCE_GENERIC") == nullptr) ? 1 : 0;
+        l.use_cxb = (l.mode == 1 && l.LE > 16 && l.LE <= 48 && l.S <= 2 && !(l.flags & V2VAE_FLAG_GENERIC)) ? 1 : 0;
         l.cxb_nb = (l.LE + 15) / 16;
         l.cxb_leb = 16 * l.cxb_nb;
         l.cxb_rec = 2 * l.cxb_leb * l.cxb_leb + 4 * l.cxb_leb;
@@ -159,12 +161,12 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     }
     // ---- matrix-core equaliser path: complex, second-order lags odd <= 31, centred first-order window inside it
     l.use_eqcx = (l.mode == 1 && l.l2 >= 1 && l.l2 <= 31 && (l.l1 & 1) && l.l1 <= l.l2 && l.pad1 == l.l1 / 2 &&
-                  getenv("V2VAE_FORCE_GENERIC") == nullptr) ? 1 : 0;
+                  !(l.flags & V2VAE_FLAG_GENERIC)) ? 1 : 0;
     l.eqcx_lk = (l.l2 + 2) & ~1;           // lags per stream, even and > l2 (the spare lag carries a zero coefficient)
     l.eqcx_steps = l.eqcx_lk;              // 2 streams * lk lags / 2 per MFMA step
     // blocked variant for longer kernels
     l.use_eqcxb = (l.mode == 1 && l.l2 > 31 && l.l2 <= 95 && (l.l1 & 1) && l.l1 <= l.l2 && l.pad1 == l.l1 / 2 &&
-                   getenv("V2VAE_FORCE_GENERIC") == nullptr) ? 1 : 0;
+                   !(l.flags & V2VAE_FLAG_GENERIC)) ? 1 : 0;
     l.eqcxb_nbl = (l.l2 + 32) / 32;        // 32-row blocks holding lags 0 .. l2 (row l2 carries the first-order kernel)
     l.eqcxb_fwd = (l.use_eqcxb || l.use_eqcx) ? 1 : 0;  // the blocked forward kernel also serves the one-block case
     l.eqcxb_rec = 2 * (l.eqcxb_nbl * (l.eqcxb_nbl + 1) / 2) * 1024;
@@ -1668,6 +1670,14 @@ int v2vae_demap_moments(const v2vae_problem* p, const float* xhat, const float* 
     else if (l.C <= 8) V2VAE_LAUNCH_DEMAP(8);
     else V2VAE_LAUNCH_DEMAP(16);
 #undef V2VAE_LAUNCH_DEMAP
+    return launch_status();
+}
+
+int v2vae_elbo_prepass(const v2vae_problem* p, void* ws, void* stream) {
+    Lay l;
+    int rc = make_layout(p, &l);
+    if (rc) return rc;
+    if (!ws) return V2VAE_EINVAL;
     if (l.use_cx || l.use_cxb) launch_psum_cx(l, (float*)ws, (hipStream_t)stream);
     return launch_status();
 }
@@ -1850,6 +1860,7 @@ int v2vae_train_step(const v2vae_problem* p, const v2vae_train_args* a, void* st
     if ((rc = v2vae_prep_tables(p, h1, h2, k1, n[3] ? k2 : nullptr, a->ws, stream))) return rc;
     if ((rc = v2vae_eq_fwd(p, a->y, a->ws, a->xhat, stream))) return rc;
     if ((rc = v2vae_demap_moments(p, a->xhat, a->levels, a->prior, sc, a->noise_var, a->ws, nullptr, stream))) return rc;
+    if ((rc = v2vae_elbo_prepass(p, a->ws, stream))) return rc;
     if ((rc = v2vae_elbo_fused(p, a->y, a->ws, stream))) return rc;
     {
         Lay l;

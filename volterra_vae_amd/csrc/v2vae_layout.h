@@ -39,6 +39,7 @@ struct Lay {
     // diagonal second-order kernel); 2 Hammerstein (one filter h [L] on alpha1 x + alpha2 x^2; the h2 section is
     // [alpha1, alpha2]).  1 and 2 run the same kernels on tables built with a diagonal kernel.
     int chan;
+    int flags;               // v2vae_problem::flags (V2VAE_FLAG_*): A/B switches between two HIP kernels for one shape
     int64_t n_glob, y_lo, y_len, sym_lo, sym_cnt, own_lo, own_cnt;
     int64_t y_stride;  // floats between the ns sample streams (y_len unless a batch is a slice of a longer sequence)
     int pre;                 // (L-1)/2: y' = y[pre + n]

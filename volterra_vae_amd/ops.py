@@ -36,9 +36,10 @@ class Plan:
     """Geometry + workspace for one (batch length, model shape, owned slice) combination."""
 
     def __init__(self, *, ns, sps, l1, pad1, l2, L, C_levels, n_glob, device,
-                 y_lo=0, y_len=None, sym_lo=0, sym_cnt=None, own_lo=None, own_cnt=None, mode=None):
+                 y_lo=0, y_len=None, sym_lo=0, sym_cnt=None, own_lo=None, own_cnt=None, mode=None, flags=None):
         b_glob = n_glob // sps
         p = Problem()
+        p.flags = _lib.default_flags() if flags is None else flags
         mode = (0 if ns == 1 else 1) if mode is None else mode  # 2 / 3: memory-polynomial / Hammerstein channel (real)
         p.ns, p.mode, p.sps, p.l1, p.pad1, p.l2, p.L, p.C = ns, mode, sps, l1, pad1, l2, L, C_levels
         p.n_glob, p.y_lo = n_glob, y_lo
@@ -56,9 +57,15 @@ class Plan:
         self.gxhat = torch.zeros((ns, p.sym_cnt), dtype=torch.float32, device=device)
         self.sizes = _lib.pack_sizes(p)
         self.W = n_glob - L + 1
+        # Counts the calls that overwrite what the ELBO's backward reads from the workspace (channel tables, moments,
+        # dE/d(moments), partial records, the scalar block).  ElboLossFn notes it at forward and re-runs its forward stages
+        # in backward if anything ran on this plan in between.
+        self.elbo_generation = 0
 
     # --- individual stages ---------------------------------------------------------------
     def prep_tables(self, h1=None, h2=None, k1=None, k2=None):
+        if h1 is not None:
+            self.elbo_generation += 1
         check(lib.v2vae_prep_tables(C.byref(self.p), _ptr(h1), _ptr(h2), _ptr(k1), _ptr(k2), _ptr(self.ws), _stream()),
               "v2vae_prep_tables")
 
@@ -66,16 +73,27 @@ class Plan:
         check(lib.v2vae_eq_fwd(C.byref(self.p), _ptr(y), _ptr(self.ws), _ptr(xhat), _stream()), "v2vae_eq_fwd")
 
     def demap_moments(self, xhat, levels, prior, scaling, noise_var, q_out=None):
+        self.elbo_generation += 1
         check(lib.v2vae_demap_moments(C.byref(self.p), _ptr(xhat), _ptr(levels), _ptr(prior), _ptr(scaling), _ptr(noise_var),
                                       _ptr(self.ws), _ptr(q_out), _stream()), "v2vae_demap_moments")
 
-    def elbo_fused(self, y):
+    def elbo_prepass(self):
+        self.elbo_generation += 1
+        check(lib.v2vae_elbo_prepass(C.byref(self.p), _ptr(self.ws), _stream()), "v2vae_elbo_prepass")
+
+    def elbo_fused(self, y, prepass=True):
+        """ELBO forward + unscaled backward; `prepass=False` if elbo_prepass() was already called for these moments."""
+        if prepass:
+            self.elbo_prepass()
+        self.elbo_generation += 1
         check(lib.v2vae_elbo_fused(C.byref(self.p), _ptr(y), _ptr(self.ws), _stream()), "v2vae_elbo_fused")
 
     def reduce_scalars(self):
+        self.elbo_generation += 1
         check(lib.v2vae_reduce_scalars(C.byref(self.p), _ptr(self.ws), _ptr(self.scal), _stream()), "v2vae_reduce_scalars")
 
     def finalize_scalars(self):
+        self.elbo_generation += 1
         check(lib.v2vae_finalize_scalars(C.byref(self.p), _ptr(self.scal), _stream()), "v2vae_finalize_scalars")
 
     def sym_bwd(self, xhat, levels, prior, scaling, noise_var, grad_scale=None, gxhat=None):
@@ -112,6 +130,7 @@ class Plan:
     def train_step(self, *, y, levels, prior, params, grads, adam_m, adam_v, adam_vmax, noise_var, xhat, loss_out,
                    lr, step, beta1=0.9, beta2=0.999, eps=1e-8, learn_scaling=True, adaptive_noise=True, freeze_h2=False,
                    accumulate_scaling_grad=False):
+        self.elbo_generation += 1
         a = TrainArgs()
         a.y, a.levels, a.prior = y.data_ptr(), levels.data_ptr(), prior.data_ptr()
         a.params, a.grads = params.data_ptr(), grads.data_ptr()
@@ -147,8 +166,9 @@ class PersistentFit:
     (one workgroup per model): the mini-batch loop of lib/real_equalization.py:482-502 without a launch or a
     host round trip per batch.  All state tensors carry a leading model dimension."""
 
-    def __init__(self, *, ns, sps, l1, pad1, l2, L, C_levels, batch_symbols, n_models, device, mode=None):
+    def __init__(self, *, ns, sps, l1, pad1, l2, L, C_levels, batch_symbols, n_models, device, mode=None, flags=None):
         p = Problem()
+        p.flags = _lib.default_flags() if flags is None else flags
         mode = (0 if ns == 1 else 1) if mode is None else mode
         p.ns, p.mode, p.sps, p.l1, p.pad1, p.l2, p.L, p.C = ns, mode, sps, l1, pad1, l2, L, C_levels
         p.n_glob = p.y_len = batch_symbols * sps
@@ -245,21 +265,30 @@ class EqualiserFn(torch.autograd.Function):
 
 
 class ElboLossFn(torch.autograd.Function):
-    """loss = KL + W log E through the fused ELBO kernels.  Returns (loss, E); E carries no gradient."""
+    """loss = KL + W log E through the fused ELBO kernels.  Returns (loss, E); E carries no gradient.
+
+    The backward reads dE/d(moments), the partial records and W / E from the plan's workspace.  If anything else ran on
+    the plan between this forward and its backward (another loss, an inference call of the same length), the forward
+    stages are run again from the saved inputs first, so any interleaving autograd allows gives the right gradients."""
 
     @staticmethod
-    def forward(ctx, plan: Plan, xhat, y, h1, h2, scaling, noise_var, levels, prior):
-        _require_gpu_f32(y, "y")
-        xh = xhat.detach().contiguous()
-        h1c, h2c, scc = h1.detach().contiguous(), h2.detach().contiguous(), scaling.detach().contiguous()
-        nv = noise_var.detach().clone()
+    def _forward_stages(plan, xh, y, h1c, h2c, scc, nv, levels, prior):
         plan.prep_tables(h1=h1c, h2=h2c)
         plan.demap_moments(xh, levels, prior, scc, nv)
         plan.elbo_fused(y)
         plan.reduce_scalars()
         plan.finalize_scalars()
+        return plan.elbo_generation
+
+    @staticmethod
+    def forward(ctx, plan: Plan, xhat, y, h1, h2, scaling, noise_var, levels, prior):
+        _require_gpu_f32(y, "y")
+        xh = xhat.detach().contiguous()
+        h1c, h2c, scc = h1.detach().clone(), h2.detach().clone(), scaling.detach().clone()
+        nv = noise_var.detach().clone()
+        ctx.generation = ElboLossFn._forward_stages(plan, xh, y, h1c, h2c, scc, nv, levels, prior)
         ctx.plan = plan
-        ctx.save_for_backward(xh, scc, nv, levels, prior)
+        ctx.save_for_backward(xh, scc, nv, levels, prior, y, h1c, h2c)
         ctx.shapes = (h1.shape, h2.shape, scaling.shape, xhat.shape)
         sc = plan.scal.clone()
         loss = sc[_lib.SCAL_LOSS].to(torch.float32)
@@ -270,7 +299,9 @@ class ElboLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gloss, _gE):
         plan = ctx.plan
-        xh, scc, nv, levels, prior = ctx.saved_tensors
+        xh, scc, nv, levels, prior, y, h1c, h2c = ctx.saved_tensors
+        if plan.elbo_generation != ctx.generation:
+            ctx.generation = ElboLossFn._forward_stages(plan, xh, y, h1c, h2c, scc, nv, levels, prior)
         gs = gloss.detach().to(torch.float32).reshape(1).contiguous()
         gx = torch.empty_like(xh)
         plan.sym_bwd(xh, levels, prior, scc, nv, grad_scale=gs, gxhat=gx)
