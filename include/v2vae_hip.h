@@ -6,7 +6,8 @@
  * 0 on success or a negative V2VAE_E* code.  Nothing here allocates, frees or synchronises;
  * the caller owns every buffer, including the workspace (size from v2vae_workspace_bytes).
  * Calls on different streams / devices with different workspaces are independent; the only process-wide state is the
- * calling thread's last-error text and the per-kernel LDS-size attribute the launchers set.
+ * calling thread's last-error text, the per-kernel LDS-size attribute the launchers set, and the per-device address of the
+ * static scratch of v2vae_train_step_static.
  *
  * The reference has no FFI; the functions it exposes for this path are Python methods.  Each
  * entry point cites the reference code whose arithmetic it replaces (paths under the reference
@@ -183,6 +184,18 @@ typedef struct v2vae_train_args {
  * (lib/real_equalization.py:488-496): forward, ELBO, backward, Adam-AMSGrad update, all enqueued
  * on `stream` with no host synchronisation. */
 int v2vae_train_step(const v2vae_problem* p, const v2vae_train_args* a, void* stream);
+
+/* The same step for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  No counterpart in the reference.  Workspace, scalar block and per-symbol gradient buffer come from
+ * one static device array of V2VAE_STATIC_SCRATCH_BYTES inside the library (every GPU the library runs on holds its own copy
+ * until the process ends); a->ws, a->scal and a->gxhat must be NULL, every other field is as for v2vae_train_step and the
+ * results are bit-identical to it.  Calls no hipMalloc / hipFree or any other allocating routine.  V2VAE_ESIZE (and a
+ * v2vae_last_error text with both sizes) if v2vae_static_scratch_bytes(p) exceeds the array.  All calls on one GPU share that
+ * GPU's array: it is cleared at the start of every call, and two calls that overlap in time on one GPU (different streams or
+ * threads) race - serialise them. */
+#define V2VAE_STATIC_SCRATCH_BYTES (32u << 20)
+size_t v2vae_static_scratch_bytes(const v2vae_problem* p); /* bytes of the array this problem would use; 0 if invalid */
+int v2vae_train_step_static(const v2vae_problem* p, const v2vae_train_args* a, void* stream);
 
 typedef struct v2vae_fit_args {
     const float* y;           /* model m, stream c, sample i of batch n: y[m*y_model_stride + c*y_stream_stride + n*B*sps + i] */

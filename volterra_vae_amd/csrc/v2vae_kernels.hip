@@ -12,6 +12,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "v2vae_layout.h"
 #include "v2vae_posterior.h"
 
@@ -1882,6 +1884,92 @@ int v2vae_train_step(const v2vae_problem* p, const v2vae_train_args* a, void* st
     return v2vae_adam_amsgrad(nadam - first, a->params + first, g + first, a->adam_m + first, a->adam_v + first,
                               a->adam_vmax + first, a->lr, a->beta1, a->beta2, a->eps, a->step, a->scal,
                               a->adaptive_noise ? a->noise_var : nullptr, a->loss_out, stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// v2vae_train_step_static: the whole step with no allocation by anyone.  Workspace, scalar block and the per-symbol
+// gradient buffer of v2vae_train_step are carved out of one static device array.  `static_scratch` below is only the
+// host-side handle of that array: host code must never pass it to a kernel or a memset; the per-device address comes from
+// hipGetSymbolAddress (each GPU has its own copy of the array at its own address) and only that pointer is used.
+// ------------------------------------------------------------------------------------------
+static __device__ __align__(256) unsigned char static_scratch[V2VAE_STATIC_SCRATCH_BYTES];
+
+namespace {
+constexpr int STATIC_MAX_DEVICES = 64;
+std::mutex g_static_mutex;
+void* g_static_ptr[STATIC_MAX_DEVICES] = {};  // device address of static_scratch per device ordinal, filled at first use
+
+// Address of the calling thread's current device's copy of the array (resolved once per device).
+int static_scratch_ptr(unsigned char** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= STATIC_MAX_DEVICES) {
+        snprintf(g_last_error, sizeof(g_last_error), "v2vae_train_step_static: hipGetDevice: %s (device %d)",
+                 hipGetErrorString(e), dev);
+        return V2VAE_ELAUNCH;
+    }
+    std::lock_guard<std::mutex> lock(g_static_mutex);
+    if (!g_static_ptr[dev]) {
+        void* ptr = nullptr;
+        e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(static_scratch));
+        if (e != hipSuccess || !ptr) {
+            snprintf(g_last_error, sizeof(g_last_error), "v2vae_train_step_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
+            return V2VAE_ELAUNCH;
+        }
+        g_static_ptr[dev] = ptr;
+    }
+    *out = static_cast<unsigned char*>(g_static_ptr[dev]);
+    return V2VAE_OK;
+}
+
+// carve of the static array: [scal: 8 doubles | gxhat: ns * sym_cnt floats | workspace], every part 256-byte aligned
+struct StaticCarve {
+    size_t o_scal, o_gxhat, o_ws, ws_bytes, total;
+};
+int static_carve(const v2vae_problem* p, StaticCarve* c) {
+    Lay l;
+    const int rc = make_layout(p, &l);
+    if (rc) return rc;
+    c->o_scal = 0;
+    c->o_gxhat = (size_t)rup(V2VAE_SCAL_COUNT * sizeof(double), 256);
+    c->o_ws = c->o_gxhat + (size_t)rup((int64_t)l.ns * l.sym_cnt * sizeof(float), 256);
+    c->ws_bytes = (size_t)l.total_floats * sizeof(float);
+    c->total = c->o_ws + (size_t)rup((int64_t)c->ws_bytes, 256);
+    return V2VAE_OK;
+}
+}  // namespace
+
+size_t v2vae_static_scratch_bytes(const v2vae_problem* p) {
+    StaticCarve c;
+    if (!p || static_carve(p, &c) != V2VAE_OK) return 0;
+    return c.total;
+}
+
+int v2vae_train_step_static(const v2vae_problem* p, const v2vae_train_args* a, void* stream) {
+    if (!p || !a) return V2VAE_EINVAL;
+    if (a->ws || a->scal || a->gxhat) return V2VAE_EINVAL;  // these three live in the static array
+    StaticCarve c;
+    int rc = static_carve(p, &c);
+    if (rc) return rc;
+    if (c.total > (size_t)V2VAE_STATIC_SCRATCH_BYTES) {
+        snprintf(g_last_error, sizeof(g_last_error),
+                 "v2vae_train_step_static: this problem needs %zu bytes of scratch, the static array holds %zu; use "
+                 "v2vae_train_step with a caller-owned workspace", c.total, (size_t)V2VAE_STATIC_SCRATCH_BYTES);
+        return V2VAE_ESIZE;
+    }
+    unsigned char* base = nullptr;
+    if ((rc = static_scratch_ptr(&base))) return rc;
+    // the array keeps the previous call's contents: start every call from the all-zero state a fresh workspace has
+    const hipError_t e = hipMemsetAsync(base, 0, c.total, (hipStream_t)stream);
+    if (e != hipSuccess) {
+        snprintf(g_last_error, sizeof(g_last_error), "v2vae_train_step_static: hipMemsetAsync: %s", hipGetErrorString(e));
+        return V2VAE_ELAUNCH;
+    }
+    v2vae_train_args b = *a;
+    b.scal = reinterpret_cast<double*>(base + c.o_scal);
+    b.gxhat = reinterpret_cast<float*>(base + c.o_gxhat);
+    b.ws = base + c.o_ws;
+    return v2vae_train_step(p, &b, stream);
 }
 
 int v2vae_adam_schedule(int64_t step0, int64_t n, const float* lr, float beta1, float beta2, float* step_size,

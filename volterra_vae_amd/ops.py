@@ -129,7 +129,7 @@ class Plan:
     # --- whole fused step ------------------------------------------------------------------
     def train_step(self, *, y, levels, prior, params, grads, adam_m, adam_v, adam_vmax, noise_var, xhat, loss_out,
                    lr, step, beta1=0.9, beta2=0.999, eps=1e-8, learn_scaling=True, adaptive_noise=True, freeze_h2=False,
-                   accumulate_scaling_grad=False):
+                   accumulate_scaling_grad=False, static_scratch=False):
         self.elbo_generation += 1
         a = TrainArgs()
         a.y, a.levels, a.prior = y.data_ptr(), levels.data_ptr(), prior.data_ptr()
@@ -141,6 +141,10 @@ class Plan:
         a.lr, a.beta1, a.beta2, a.eps, a.step = lr, beta1, beta2, eps, step
         a.learn_scaling, a.adaptive_noise, a.freeze_h2 = int(learn_scaling), int(adaptive_noise), int(freeze_h2)
         a.accumulate_scaling_grad = int(accumulate_scaling_grad)
+        if static_scratch:  # workspace, scalars and gxhat from the library's static device array: nothing allocated by anyone
+            a.ws = a.scal = a.gxhat = None
+            check(lib.v2vae_train_step_static(C.byref(self.p), C.byref(a), _stream()), "v2vae_train_step_static")
+            return
         check(lib.v2vae_train_step(C.byref(self.p), C.byref(a), _stream()), "v2vae_train_step")
 
 
