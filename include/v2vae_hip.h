@@ -94,8 +94,11 @@ int v2vae_prep_tables(const v2vae_problem* p, const float* h1, const float* h2, 
                       const float* k2, void* ws, void* stream);
 
 /* Equaliser forward: SecondOrderVolterraSeries.forward (lib/torch_components.py:79-96) or the
- * Conv1d equaliser (lib/real_equalization.py:980-982).  xhat [ns][sym_cnt]. */
-int v2vae_eq_fwd(const v2vae_problem* p, const float* y, const void* ws, float* xhat, void* stream);
+ * Conv1d equaliser (lib/real_equalization.py:980-982).  xhat [ns][sym_cnt].  Real model: the sums are formed in double and
+ * the part of the result that does not fit the float is kept in the workspace; v2vae_demap_moments and v2vae_sym_bwd add it
+ * back when they are handed exactly this xhat (compared bitwise per symbol), which takes the fp32 rounding of xhat, amplified
+ * by 2 |xhat - a| / noise variance in the soft demapper, out of the equaliser and noise-scaling gradients. */
+int v2vae_eq_fwd(const v2vae_problem* p, const float* y, void* ws, float* xhat, void* stream);
 
 /* Soft demapping + per-symbol posterior moments + KL partial sums
  * (lib/real_equalization.py:816-823, :847, :850-865).  q_out [ns][C][sym_cnt] may be NULL.  Needs no coefficient table:
@@ -184,6 +187,19 @@ typedef struct v2vae_train_args {
  * (lib/real_equalization.py:488-496): forward, ELBO, backward, Adam-AMSGrad update, all enqueued
  * on `stream` with no host synchronisation. */
 int v2vae_train_step(const v2vae_problem* p, const v2vae_train_args* a, void* stream);
+
+/* The halo-sharded step (one rank's part of one long batch; the reference has no distributed code, its fit loop is
+ * lib/real_equalization.py:484-502) as three calls around the caller's two collectives:
+ *   v2vae_train_step_sharded_pre    forward and ELBO partial sums; local E, KL in scal[0..1]
+ *   -- all-reduce (sum) scal[0..1] over the ranks --
+ *   v2vae_train_step_sharded_post   loss and W / E from the global sums, backward, this rank's gradient sums in a->grads
+ *   -- all-reduce (sum) a->grads over the ranks --
+ *   v2vae_train_step_update         Adam-AMSGrad from a->grads (sections per learn_scaling / freeze_h2), noise variance, loss
+ * With one rank (no collectives) the three calls equal v2vae_train_step.  accumulate_scaling_grad is not supported by the
+ * sharded pair (the running sum would be all-reduced again every step). */
+int v2vae_train_step_sharded_pre(const v2vae_problem* p, const v2vae_train_args* a, void* stream);
+int v2vae_train_step_sharded_post(const v2vae_problem* p, const v2vae_train_args* a, void* stream);
+int v2vae_train_step_update(const v2vae_problem* p, const v2vae_train_args* a, void* stream);
 
 /* The same step for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses
  * that forbid hipMalloc).  No counterpart in the reference.  Workspace, scalar block and per-symbol gradient buffer come from

@@ -97,6 +97,9 @@ EXPORTS = {
     "v2vae_decide": (C.c_int, [C.POINTER(Problem)] + [C.c_void_p] * 6),
     "v2vae_pack_sizes": (None, [C.POINTER(Problem), C.POINTER(C.c_int64 * 5)]),
     "v2vae_train_step": (C.c_int, [C.POINTER(Problem), C.POINTER(TrainArgs), C.c_void_p]),
+    "v2vae_train_step_sharded_pre": (C.c_int, [C.POINTER(Problem), C.POINTER(TrainArgs), C.c_void_p]),
+    "v2vae_train_step_sharded_post": (C.c_int, [C.POINTER(Problem), C.POINTER(TrainArgs), C.c_void_p]),
+    "v2vae_train_step_update": (C.c_int, [C.POINTER(Problem), C.POINTER(TrainArgs), C.c_void_p]),
     "v2vae_train_step_static": (C.c_int, [C.POINTER(Problem), C.POINTER(TrainArgs), C.c_void_p]),
     "v2vae_static_scratch_bytes": (C.c_size_t, [C.POINTER(Problem)]),
     "v2vae_adam_schedule": (C.c_int, [C.c_int64, C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),

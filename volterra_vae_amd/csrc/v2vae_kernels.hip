@@ -197,6 +197,11 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     l.o_dc = take((int64_t)l.S * l.ns * l.LTp);
     l.o_dqc = take((int64_t)l.S * l.ns * l.LTp);
     l.o_chanraw = take(l.chan ? 2 * (int64_t)l.L : 0);
+    // real path: the equaliser output is formed in double and kept as a (float, float remainder) pair; the per-symbol kernels
+    // add the remainder back when the xhat they are handed is bitwise the one the forward kernel produced
+    l.xlo = (l.mode == 0 && l.ns == 1) ? 1 : 0;
+    l.o_xhi = take(l.xlo ? l.sym_cnt : 0);
+    l.o_xlo = take(l.xlo ? l.sym_cnt : 0);
     l.o_mom = take((int64_t)l.ns * 4 * l.sym_cnt);
     l.o_gmom = take((int64_t)l.ns * 4 * l.sym_cnt);
     l.o_part_elbo = take((int64_t)l.nblk_elbo * l.rec_elbo);
@@ -447,9 +452,12 @@ __device__ __forceinline__ void load_sample_tile(const Lay& l, const float* __re
     }
 }
 
-// one tile of EQ_TB symbols per block id
-__device__ __forceinline__ void d_eq_fwd(const GridCtx gc, Lay l, const float* __restrict__ y, const float* __restrict__ ws,
-                                         float* __restrict__ xhat) {
+// one tile of EQ_TB symbols per block id.  ACC = double (real path): the sums are exact to double rounding and the result
+// leaves as a float plus its float remainder (workspace planes o_xhi / o_xlo), because the soft demapper amplifies an error
+// of xhat by 2 |xhat - a| / noise variance (~1e2) on its way into the equaliser and noise-scaling gradients.
+template <typename ACC>
+__device__ __forceinline__ void d_eq_fwd_t(const GridCtx gc, Lay l, const float* __restrict__ y, float* __restrict__ ws,
+                                           float* __restrict__ xhat) {
     extern __shared__ float sm[];
     float* tile = sm;
     const int64_t b0 = l.sym_lo + (int64_t)gc.bid * EQ_TB;
@@ -460,30 +468,30 @@ __device__ __forceinline__ void d_eq_fwd(const GridCtx gc, Lay l, const float* _
     const int base = threadIdx.x * l.S + l.hl;
     const float* __restrict__ K1 = ws + l.o_eqK1;
     const float* __restrict__ K2 = ws + l.o_eqK2;
-    float out[2] = {0.f, 0.f};
+    ACC out[2] = {0, 0};
     for (int c = 0; c < l.ns; ++c)
         for (int j = 0; j < l.l1; ++j) {
-            const float x = tile[c * l.tile_len + base - l.pad1 + j];
+            const ACC x = tile[c * l.tile_len + base - l.pad1 + j];
 #pragma unroll
             for (int o = 0; o < 2; ++o)
-                if (o < l.ns) out[o] = fmaf(K1[(o * l.ns + c) * l.l1 + j], x, out[o]);
+                if (o < l.ns) out[o] = fma((ACC)K1[(o * l.ns + c) * l.l1 + j], x, out[o]);
         }
     if (l.l2 > 0) {
         const int nb = l.LT2p / 4;
         for (int ib = 0; ib < nb; ++ib) {
-            float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            ACC acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
             for (int c = 0; c < l.ns; ++c)
                 for (int j = 0; j < l.l2; ++j) {
-                    const float x = tile[c * l.tile_len + base + l.p2 - j];
+                    const ACC x = tile[c * l.tile_len + base + l.p2 - j];
                     const int ip = c * l.l2 + j;
 #pragma unroll
                     for (int o = 0; o < 2; ++o)
                         if (o < l.ns) {
                             const float4 kv = *reinterpret_cast<const float4*>(K2 + ((size_t)o * l.LT2p + ip) * l.LT2p + ib * 4);
-                            acc[o][0] = fmaf(kv.x, x, acc[o][0]);
-                            acc[o][1] = fmaf(kv.y, x, acc[o][1]);
-                            acc[o][2] = fmaf(kv.z, x, acc[o][2]);
-                            acc[o][3] = fmaf(kv.w, x, acc[o][3]);
+                            acc[o][0] = fma((ACC)kv.x, x, acc[o][0]);
+                            acc[o][1] = fma((ACC)kv.y, x, acc[o][1]);
+                            acc[o][2] = fma((ACC)kv.z, x, acc[o][2]);
+                            acc[o][3] = fma((ACC)kv.w, x, acc[o][3]);
                         }
                 }
 #pragma unroll
@@ -491,20 +499,41 @@ __device__ __forceinline__ void d_eq_fwd(const GridCtx gc, Lay l, const float* _
                 const int ii = ib * 4 + i;
                 if (ii < l.LT2) {
                     const int c = ii / l.l2, j = ii - c * l.l2;
-                    const float xi = tile[c * l.tile_len + base + l.p2 - j];
+                    const ACC xi = tile[c * l.tile_len + base + l.p2 - j];
 #pragma unroll
                     for (int o = 0; o < 2; ++o)
-                        if (o < l.ns) out[o] = fmaf(xi, acc[o][i], out[o]);
+                        if (o < l.ns) out[o] = fma(xi, acc[o][i], out[o]);
                 }
             }
         }
     }
-    for (int o = 0; o < l.ns; ++o) xhat[(int64_t)o * l.sym_cnt + (b - l.sym_lo)] = out[o];
+    for (int o = 0; o < l.ns; ++o) {
+        const float hi = (float)out[o];
+        xhat[(int64_t)o * l.sym_cnt + (b - l.sym_lo)] = hi;
+        if (sizeof(ACC) == sizeof(double) && l.xlo) {   // ns == 1
+            ws[l.o_xhi + (b - l.sym_lo)] = hi;
+            ws[l.o_xlo + (b - l.sym_lo)] = (float)(out[o] - (ACC)hi);
+        }
+    }
 }
 
-__global__ __launch_bounds__(NT) void k_eq_fwd(Lay l, const float* __restrict__ y, const float* __restrict__ ws,
+__device__ __forceinline__ void d_eq_fwd(const GridCtx gc, Lay l, const float* __restrict__ y, float* __restrict__ ws,
+                                         float* __restrict__ xhat) {
+    if (l.xlo) d_eq_fwd_t<double>(gc, l, y, ws, xhat);
+    else d_eq_fwd_t<float>(gc, l, y, ws, xhat);
+}
+
+__global__ __launch_bounds__(NT) void k_eq_fwd(Lay l, const float* __restrict__ y, float* __restrict__ ws,
                                                float* __restrict__ xhat) {
     d_eq_fwd(GridCtx{(int)blockIdx.x, (int)gridDim.x}, l, y, ws, xhat);
+}
+
+// The equaliser output at local symbol i in double: the float the caller holds plus, if that float is bitwise the one the
+// forward kernel produced, the remainder the kernel kept (real path only; otherwise just the float).
+__device__ __forceinline__ double xhat_full(const Lay& l, const float* __restrict__ ws, int64_t i, float x) {
+    if (!l.xlo) return (double)x;
+    const float hi = ws[l.o_xhi + i];
+    return __float_as_uint(hi) == __float_as_uint(x) ? (double)x + (double)ws[l.o_xlo + i] : (double)x;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -542,7 +571,7 @@ __device__ __forceinline__ void d_demap_moments(const GridCtx gc, Lay l, const f
         for (int c = 0; c < 2; ++c) {
             if (c >= l.ns) break;
             Posterior p;
-            posterior<CB>(cx[c], levels + c * l.C, inv_den[c], l.C, p);
+            posterior<CB>(xhat_full(l, ws, i, cx[c]), levels + c * l.C, inv_den[c], l.C, p);
             float* m = mom + (int64_t)c * 4 * l.sym_cnt + i;
             m[0] = p.mu; m[l.sym_cnt] = p.var; m[2 * l.sym_cnt] = p.kap; m[3 * l.sym_cnt] = p.gam;
             float klb = 0.f;
@@ -655,7 +684,7 @@ __device__ __forceinline__ void d_sym_bwd(const GridCtx gc, Lay l, const float* 
             if (c < l.ns) {
                 float gx = 0.f;
                 if (own) {
-                    const float x = cx[c];
+                    const double x = xhat_full(l, ws, i, cx[c]);
                     const float* lv = levels + c * l.C;
                     Posterior p;
                     posterior<CB>(x, lv, inv_den[c], l.C, p);
@@ -685,7 +714,7 @@ __device__ __forceinline__ void d_sym_bwd(const GridCtx gc, Lay l, const float* 
                             for (int j = 0; j < CB; ++j)
                                 if (j < l.C && j != k) sk = fmaf(p.q[j], v[k] - v[j], sk);
                             const float dz = p.q[k] * sk;
-                            const float df = x - lv[k];
+                            const float df = (float)(x - (double)lv[k]);
                             gxa = fmaf(dz, -2.f * df * idn_f[c][k], gxa);
                             gs[c][k] = fmaf(dz * df, df * idn_sc[c][k], gs[c][k]);
                         }
@@ -1642,7 +1671,7 @@ int v2vae_prep_tables(const v2vae_problem* p, const float* h1, const float* h2, 
     return launch_status();
 }
 
-int v2vae_eq_fwd(const v2vae_problem* p, const float* y, const void* ws, float* xhat, void* stream) {
+int v2vae_eq_fwd(const v2vae_problem* p, const float* y, void* ws, float* xhat, void* stream) {
     Lay l;
     int rc = make_layout(p, &l);
     if (rc) return rc;
@@ -1654,7 +1683,7 @@ int v2vae_eq_fwd(const v2vae_problem* p, const float* y, const void* ws, float* 
     rc = allow_lds(k_eq_fwd, l.lds_eq);
     if (rc) return rc;
     const int nblk = (int)((l.sym_cnt + EQ_TB - 1) / EQ_TB);
-    hipLaunchKernelGGL(k_eq_fwd, dim3(nblk), dim3(NT), l.lds_eq, (hipStream_t)stream, l, y, (const float*)ws, xhat);
+    hipLaunchKernelGGL(k_eq_fwd, dim3(nblk), dim3(NT), l.lds_eq, (hipStream_t)stream, l, y, (float*)ws, xhat);
     return launch_status();
 }
 
@@ -1848,34 +1877,62 @@ void v2vae_pack_sizes(const v2vae_problem* p, int64_t out[5]) {
     out[4] = (int64_t)p->ns * p->C;
 }
 
-int v2vae_train_step(const v2vae_problem* p, const v2vae_train_args* a, void* stream) {
-    if (!p || !a) return V2VAE_EINVAL;
+namespace {
+struct PackPtrs {
     int64_t n[5];
-    v2vae_pack_sizes(p, n);
-    float* h1 = a->params;
-    float* h2 = h1 + n[0];
-    float* k1 = h2 + n[1];
-    float* k2 = k1 + n[2];
-    float* sc = k2 + n[3];
-    float* g = a->grads;
+    float *h1, *h2, *k1, *k2, *sc;
+    float *g_h1, *g_h2, *g_k1, *g_k2, *g_sc;
+};
+PackPtrs pack_ptrs(const v2vae_problem* p, const v2vae_train_args* a) {
+    PackPtrs q;
+    v2vae_pack_sizes(p, q.n);
+    q.h1 = a->params;
+    q.h2 = q.h1 + q.n[0];
+    q.k1 = q.h2 + q.n[1];
+    q.k2 = q.n[3] ? q.k1 + q.n[2] : nullptr;
+    q.sc = q.k1 + q.n[2] + q.n[3];
+    q.g_h1 = a->grads;
+    q.g_h2 = q.g_h1 + q.n[0];
+    q.g_k1 = q.g_h2 + q.n[1];
+    q.g_k2 = q.n[3] ? q.g_k1 + q.n[2] : nullptr;
+    q.g_sc = q.g_k1 + q.n[2] + q.n[3];
+    return q;
+}
+}  // namespace
+
+// forward + ELBO partial sums of this rank; leaves the local E and KL in scal[0..1]
+int v2vae_train_step_sharded_pre(const v2vae_problem* p, const v2vae_train_args* a, void* stream) {
+    if (!p || !a || !a->params || !a->ws || !a->scal) return V2VAE_EINVAL;
+    const PackPtrs q = pack_ptrs(p, a);
     int rc;
-    if ((rc = v2vae_prep_tables(p, h1, h2, k1, n[3] ? k2 : nullptr, a->ws, stream))) return rc;
+    if ((rc = v2vae_prep_tables(p, q.h1, q.h2, q.k1, q.k2, a->ws, stream))) return rc;
     if ((rc = v2vae_eq_fwd(p, a->y, a->ws, a->xhat, stream))) return rc;
-    if ((rc = v2vae_demap_moments(p, a->xhat, a->levels, a->prior, sc, a->noise_var, a->ws, nullptr, stream))) return rc;
+    if ((rc = v2vae_demap_moments(p, a->xhat, a->levels, a->prior, q.sc, a->noise_var, a->ws, nullptr, stream))) return rc;
     if ((rc = v2vae_elbo_prepass(p, a->ws, stream))) return rc;
     if ((rc = v2vae_elbo_fused(p, a->y, a->ws, stream))) return rc;
-    {
-        Lay l;
-        if ((rc = make_layout(p, &l))) return rc;
-        if (!a->ws || !a->scal) return V2VAE_EINVAL;
-        hipLaunchKernelGGL(k_reduce_finalize_scalars, dim3(1), dim3(NT), 0, (hipStream_t)stream, l, (const float*)a->ws, a->scal);
-    }
-    if ((rc = v2vae_sym_bwd(p, a->xhat, a->levels, a->prior, sc, a->noise_var, a->scal, nullptr, a->ws, a->gxhat, stream))) return rc;
+    return v2vae_reduce_scalars(p, a->ws, a->scal, stream);
+}
+
+// given the GLOBAL E and KL in scal[0..1]: loss, W / E, backward, this rank's gradient sums into a->grads
+int v2vae_train_step_sharded_post(const v2vae_problem* p, const v2vae_train_args* a, void* stream) {
+    if (!p || !a || !a->params || !a->grads || !a->ws || !a->scal) return V2VAE_EINVAL;
+    const PackPtrs q = pack_ptrs(p, a);
+    int rc;
+    if ((rc = v2vae_finalize_scalars(p, a->scal, stream))) return rc;
+    if ((rc = v2vae_sym_bwd(p, a->xhat, a->levels, a->prior, q.sc, a->noise_var, a->scal, nullptr, a->ws, a->gxhat, stream))) return rc;
     if ((rc = v2vae_eq_bwd(p, a->y, a->gxhat, a->ws, stream))) return rc;
-    if ((rc = v2vae_finish_grads(p, a->ws, a->scal, nullptr, a->accumulate_scaling_grad ? 15 : 7, g, g + n[0], g + n[0] + n[1], n[3] ? g + n[0] + n[1] + n[2] : nullptr,
-                                 g + n[0] + n[1] + n[2] + n[3], stream))) return rc;
+    return v2vae_finish_grads(p, a->ws, a->scal, nullptr, 7, q.g_h1, q.g_h2, q.g_k1, q.g_k2, q.g_sc, stream);
+}
+
+// Adam-AMSGrad on the sections the model trains, from a->grads (after the caller's all-reduce in the sharded step)
+int v2vae_train_step_update(const v2vae_problem* p, const v2vae_train_args* a, void* stream) {
+    if (!p || !a || !a->params || !a->grads) return V2VAE_EINVAL;
+    int64_t n[5];
+    v2vae_pack_sizes(p, n);
+    float* g = a->grads;
     const int64_t nadam = n[0] + n[1] + n[2] + n[3] + (a->learn_scaling ? n[4] : 0);
     int64_t first = 0;
+    int rc;
     if (a->freeze_h2) {  // update [h1] and [k1 | k2 | scaling] only
         if ((rc = v2vae_adam_amsgrad(n[0], a->params, g, a->adam_m, a->adam_v, a->adam_vmax, a->lr, a->beta1, a->beta2, a->eps,
                                      a->step, nullptr, nullptr, nullptr, stream))) return rc;
@@ -1884,6 +1941,28 @@ int v2vae_train_step(const v2vae_problem* p, const v2vae_train_args* a, void* st
     return v2vae_adam_amsgrad(nadam - first, a->params + first, g + first, a->adam_m + first, a->adam_v + first,
                               a->adam_vmax + first, a->lr, a->beta1, a->beta2, a->eps, a->step, a->scal,
                               a->adaptive_noise ? a->noise_var : nullptr, a->loss_out, stream);
+}
+
+int v2vae_train_step(const v2vae_problem* p, const v2vae_train_args* a, void* stream) {
+    if (!p || !a) return V2VAE_EINVAL;
+    const PackPtrs q = pack_ptrs(p, a);
+    int rc;
+    if ((rc = v2vae_prep_tables(p, q.h1, q.h2, q.k1, q.k2, a->ws, stream))) return rc;
+    if ((rc = v2vae_eq_fwd(p, a->y, a->ws, a->xhat, stream))) return rc;
+    if ((rc = v2vae_demap_moments(p, a->xhat, a->levels, a->prior, q.sc, a->noise_var, a->ws, nullptr, stream))) return rc;
+    if ((rc = v2vae_elbo_prepass(p, a->ws, stream))) return rc;
+    if ((rc = v2vae_elbo_fused(p, a->y, a->ws, stream))) return rc;
+    {
+        Lay l;
+        if ((rc = make_layout(p, &l))) return rc;
+        if (!a->ws || !a->scal) return V2VAE_EINVAL;
+        hipLaunchKernelGGL(k_reduce_finalize_scalars, dim3(1), dim3(NT), 0, (hipStream_t)stream, l, (const float*)a->ws, a->scal);
+    }
+    if ((rc = v2vae_sym_bwd(p, a->xhat, a->levels, a->prior, q.sc, a->noise_var, a->scal, nullptr, a->ws, a->gxhat, stream))) return rc;
+    if ((rc = v2vae_eq_bwd(p, a->y, a->gxhat, a->ws, stream))) return rc;
+    if ((rc = v2vae_finish_grads(p, a->ws, a->scal, nullptr, a->accumulate_scaling_grad ? 15 : 7, q.g_h1, q.g_h2, q.g_k1, q.g_k2,
+                                 q.g_sc, stream))) return rc;
+    return v2vae_train_step_update(p, a, stream);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -84,6 +84,8 @@ struct Lay {
     int rec_elbo, rec_eq, rec_sym;
     // workspace offsets in floats
     int64_t o_eqK1, o_eqK2, o_h1c, o_Hc, o_HHc, o_dc, o_dqc, o_mom, o_gmom;
+    int xlo;                 // 1: the equaliser output carries a float remainder (real path), planes o_xhi (copy of xhat) / o_xlo
+    int64_t o_xhi, o_xlo;
     int64_t o_chanraw;       // chan != 0: copy of the raw channel sections [h1 (L) | h2 section] for the chain rule
     int64_t o_part_elbo, o_part_eq, o_part_sym, o_tot_elbo, o_tot_eq, o_tot_sym;
     int64_t o_Epart, o_KLpart;  // doubles, offsets still in floats (8-byte aligned)

@@ -23,7 +23,7 @@ __device__ __forceinline__ void posterior_temperatures(const float* __restrict__
 }
 
 template <int CB>
-__device__ __forceinline__ void posterior(float x, const float* __restrict__ lv, const double (&inv_den)[MAX_C], int C,
+__device__ __forceinline__ void posterior(double x, const float* __restrict__ lv, const double (&inv_den)[MAX_C], int C,
                                           Posterior& p) {
     // Logits reach |z| ~ 1e2..1e3 for small noise variance; rounding them to fp32 before the max is
     // subtracted would put ~|z| * 6e-8 of absolute error into the exponent, i.e. that much RELATIVE
@@ -33,7 +33,7 @@ __device__ __forceinline__ void posterior(float x, const float* __restrict__ lv,
 #pragma unroll
     for (int i = 0; i < CB; ++i)
         if (i < C) {
-            const double d = (double)x - (double)lv[i];
+            const double d = x - (double)lv[i];
             zd[i] = -(d * d) * inv_den[i];
             mx = fmax(mx, zd[i]);
         }
@@ -41,9 +41,13 @@ __device__ __forceinline__ void posterior(float x, const float* __restrict__ lv,
 #pragma unroll
     for (int i = 0; i < CB; ++i)
         if (i < C) {
-            // the argument is <= 0 and already a difference: the hardware exponential (1 ulp, flushes below 1e-38) loses
-            // nothing against the library one here and costs a fifth of its instructions
-            p.q[i] = __expf((float)(zd[i] - mx));
+            // exp(t), t <= 0 a difference formed in double.  Rounding t to float first would put |t| * 6e-8 of RELATIVE
+            // error into q (1e-5 at t = -150), and the gradients of a peaked posterior are proportional to exactly those
+            // small q.  So the range reduction t log2(e) = n + f is done in double and only f in [-1/2, 1/2] goes through the
+            // hardware exponential (1 ulp); 2^n is applied exactly (flushes to 0 below 2^-149 like the library function).
+            const double t2 = (zd[i] - mx) * 1.4426950408889634;
+            const double nr = rint(t2);
+            p.q[i] = ldexpf(__builtin_amdgcn_exp2f((float)(t2 - nr)), (int)fmax(nr, -400.0));
             sum += p.q[i];
         }
     const float inv = __builtin_amdgcn_rcpf(sum);  // sum is in [1, C]

@@ -8,7 +8,7 @@ gradients of its symbols.  To do that without any exchange of activations it hol
   * received samples for those symbols plus the equaliser's lag halo,
 with zero padding only at the two global ends, i.e. exactly the un-sharded single big batch.
 Per step there are two collectives, both tiny: the scalars [E, KL] (2 doubles) and the flat
-gradient pack.  The reference has no distributed code (its `fit` is a sequential mini-batch loop,
+gradient pack, between three calls into the library (v2vae_train_step_sharded_pre / _post, v2vae_train_step_update).  The reference has no distributed code (its `fit` is a sequential mini-batch loop,
 lib/real_equalization.py:484-502); this module is new.
 """
 from __future__ import annotations
@@ -62,27 +62,17 @@ class ShardedTrainer:
         self.dist = dist
         self.group = process_group
 
-    def step(self, *, y, levels, prior, params, grads, adam_m, adam_v, adam_vmax, noise_var, xhat, loss_out, lr, step,
-             learn_scaling=True, adaptive_noise=True, beta1=0.9, beta2=0.999, eps=1e-8):
-        from . import ops
+    def step(self, *, accumulate_scaling_grad=False, **kw):
+        """Keyword arguments as for Plan.train_args (y, levels, prior, params, grads, adam_m, adam_v, adam_vmax, noise_var,
+        xhat, loss_out, lr, step, learn_scaling, adaptive_noise, freeze_h2, betas, eps).  Three library calls and two
+        all-reduces; nothing else runs on the host between them."""
+        if accumulate_scaling_grad:
+            raise NotImplementedError("the halo-sharded step does not keep a running noise-scaling gradient "
+                                      "(memory-polynomial / Hammerstein classes): their reference semantics are per mini-batch")
         plan, dist = self.plan, self.dist
-        n = plan.sizes
-        o = [0, n[0], n[0] + n[1], n[0] + n[1] + n[2], n[0] + n[1] + n[2] + n[3], sum(n)]
-        h1, h2, k1 = params[o[0]:o[1]], params[o[1]:o[2]], params[o[2]:o[3]]
-        k2 = params[o[3]:o[4]] if n[3] else None
-        sc = params[o[4]:o[5]]
-        plan.prep_tables(h1, h2, k1, k2)
-        plan.eq_fwd(y, xhat)
-        plan.demap_moments(xhat, levels, prior, sc, noise_var)
-        plan.elbo_fused(y)
-        plan.reduce_scalars()
+        a = plan.train_args(**kw)
+        plan.sharded_pre(a)
         dist.all_reduce(plan.scal[:2], group=self.group)
-        plan.finalize_scalars()
-        gx = plan.sym_bwd(xhat, levels, prior, sc, noise_var)
-        plan.eq_bwd(y, gx)
-        plan.finish_grads(7, grads[o[0]:o[1]], grads[o[1]:o[2]], grads[o[2]:o[3]],
-                          grads[o[3]:o[4]] if n[3] else None, grads[o[4]:o[5]])
-        dist.all_reduce(grads, group=self.group)
-        nadam = o[4] + (n[4] if learn_scaling else 0)
-        ops.adam_amsgrad_(params, grads, adam_m, adam_v, adam_vmax, lr, step, beta1, beta2, eps, scal=plan.scal,
-                          noise_var=noise_var if adaptive_noise else None, loss_out=loss_out, n=nadam)
+        plan.sharded_post(a)
+        dist.all_reduce(kw["grads"], group=self.group)
+        plan.update(a)

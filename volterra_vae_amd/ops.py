@@ -7,7 +7,9 @@ ops whose forward and backward are the hand-written kernels.
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional
+import itertools
+import weakref
+from typing import Optional, Tuple
 
 import torch
 
@@ -61,6 +63,7 @@ class Plan:
         # dE/d(moments), partial records, the scalar block).  ElboLossFn notes it at forward and re-runs its forward stages
         # in backward if anything ran on this plan in between.
         self.elbo_generation = 0
+        self.handle = _register_plan(self)   # what the registered torch ops (torch.ops.v2vae.*) take in place of the object
 
     # --- individual stages ---------------------------------------------------------------
     def prep_tables(self, h1=None, h2=None, k1=None, k2=None):
@@ -127,10 +130,10 @@ class Plan:
         return self.ws[off:off + n].view(self.p.ns, 4, self.p.sym_cnt)
 
     # --- whole fused step ------------------------------------------------------------------
-    def train_step(self, *, y, levels, prior, params, grads, adam_m, adam_v, adam_vmax, noise_var, xhat, loss_out,
+    def train_args(self, *, y, levels, prior, params, grads, adam_m, adam_v, adam_vmax, noise_var, xhat, loss_out,
                    lr, step, beta1=0.9, beta2=0.999, eps=1e-8, learn_scaling=True, adaptive_noise=True, freeze_h2=False,
-                   accumulate_scaling_grad=False, static_scratch=False):
-        self.elbo_generation += 1
+                   accumulate_scaling_grad=False) -> TrainArgs:
+        """v2vae_train_args for this plan's workspace (the tensors must outlive the enqueued work)."""
         a = TrainArgs()
         a.y, a.levels, a.prior = y.data_ptr(), levels.data_ptr(), prior.data_ptr()
         a.params, a.grads = params.data_ptr(), grads.data_ptr()
@@ -141,11 +144,29 @@ class Plan:
         a.lr, a.beta1, a.beta2, a.eps, a.step = lr, beta1, beta2, eps, step
         a.learn_scaling, a.adaptive_noise, a.freeze_h2 = int(learn_scaling), int(adaptive_noise), int(freeze_h2)
         a.accumulate_scaling_grad = int(accumulate_scaling_grad)
+        return a
+
+    def train_step(self, *, static_scratch=False, **kw):
+        """One whole single-GPU training step (v2vae_train_step); keyword arguments as for train_args."""
+        self.elbo_generation += 1
+        a = self.train_args(**kw)
         if static_scratch:  # workspace, scalars and gxhat from the library's static device array: nothing allocated by anyone
             a.ws = a.scal = a.gxhat = None
             check(lib.v2vae_train_step_static(C.byref(self.p), C.byref(a), _stream()), "v2vae_train_step_static")
             return
         check(lib.v2vae_train_step(C.byref(self.p), C.byref(a), _stream()), "v2vae_train_step")
+
+    # the halo-sharded step: three calls around the caller's two all-reduces (scal[:2], then the gradient pack)
+    def sharded_pre(self, a: TrainArgs):
+        self.elbo_generation += 1
+        check(lib.v2vae_train_step_sharded_pre(C.byref(self.p), C.byref(a), _stream()), "v2vae_train_step_sharded_pre")
+
+    def sharded_post(self, a: TrainArgs):
+        self.elbo_generation += 1
+        check(lib.v2vae_train_step_sharded_post(C.byref(self.p), C.byref(a), _stream()), "v2vae_train_step_sharded_post")
+
+    def update(self, a: TrainArgs):
+        check(lib.v2vae_train_step_update(C.byref(self.p), C.byref(a), _stream()), "v2vae_train_step_update")
 
 
 def adam_amsgrad_(params, grads, m, v, vmax, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, scal=None, noise_var=None,
@@ -237,81 +258,179 @@ class PersistentFit:
 
 
 # ------------------------------------------------------------------------------------------------
-# autograd ops
+# registered torch custom ops (torch.ops.v2vae.*) over the C ABI, with autograd formulas
 # ------------------------------------------------------------------------------------------------
-class EqualiserFn(torch.autograd.Function):
-    """xhat = equaliser(y; k1, k2) through v2vae_eq_fwd / v2vae_eq_bwd.  y: [ns, N] (no gradient)."""
-
-    @staticmethod
-    def forward(ctx, plan: Plan, y, k1, k2):
-        _require_gpu_f32(y, "y")
-        k1c = k1.detach().contiguous()
-        k2c = None if k2 is None else k2.detach().contiguous()
-        plan.prep_tables(k1=k1c, k2=k2c)
-        xhat = torch.empty((plan.p.ns, plan.p.sym_cnt), dtype=torch.float32, device=y.device)
-        plan.eq_fwd(y, xhat)
-        ctx.plan = plan
-        ctx.save_for_backward(y)
-        ctx.k_shapes = (k1.shape, None if k2 is None else k2.shape)
-        return xhat
-
-    @staticmethod
-    def backward(ctx, gx):
-        plan = ctx.plan
-        (y,) = ctx.saved_tensors
-        gx = gx.contiguous()
-        plan.eq_bwd(y, gx)
-        s1, s2 = ctx.k_shapes
-        g_k1 = torch.empty(s1, dtype=torch.float32, device=y.device)
-        g_k2 = None if s2 is None else torch.empty(s2, dtype=torch.float32, device=y.device)
-        plan.finish_grads(4, g_k1=g_k1, g_k2=g_k2)
-        return None, None, g_k1, g_k2
+# A Plan (geometry + workspace) is not a tensor, so the ops take its integer handle; `plan_from_handle` resolves it.
+_PLAN_COUNTER = itertools.count(1)
+_PLANS = weakref.WeakValueDictionary()
 
 
-class ElboLossFn(torch.autograd.Function):
-    """loss = KL + W log E through the fused ELBO kernels.  Returns (loss, E); E carries no gradient.
+def plan_from_handle(handle: int) -> Plan:
+    try:
+        return _PLANS[handle]
+    except KeyError:
+        raise RuntimeError(f"v2vae: plan handle {handle} is not alive (the Plan object was released)") from None
 
-    The backward reads dE/d(moments), the partial records and W / E from the plan's workspace.  If anything else ran on
-    the plan between this forward and its backward (another loss, an inference call of the same length), the forward
-    stages are run again from the saved inputs first, so any interleaving autograd allows gives the right gradients."""
 
-    @staticmethod
-    def _forward_stages(plan, xh, y, h1c, h2c, scc, nv, levels, prior):
-        plan.prep_tables(h1=h1c, h2=h2c)
-        plan.demap_moments(xh, levels, prior, scc, nv)
-        plan.elbo_fused(y)
-        plan.reduce_scalars()
-        plan.finalize_scalars()
-        return plan.elbo_generation
+def _register_plan(plan: Plan) -> int:
+    h = next(_PLAN_COUNTER)
+    _PLANS[h] = plan
+    return h
 
-    @staticmethod
-    def forward(ctx, plan: Plan, xhat, y, h1, h2, scaling, noise_var, levels, prior):
-        _require_gpu_f32(y, "y")
-        xh = xhat.detach().contiguous()
-        h1c, h2c, scc = h1.detach().clone(), h2.detach().clone(), scaling.detach().clone()
-        nv = noise_var.detach().clone()
-        ctx.generation = ElboLossFn._forward_stages(plan, xh, y, h1c, h2c, scc, nv, levels, prior)
-        ctx.plan = plan
-        ctx.save_for_backward(xh, scc, nv, levels, prior, y, h1c, h2c)
-        ctx.shapes = (h1.shape, h2.shape, scaling.shape, xhat.shape)
-        sc = plan.scal.clone()
-        loss = sc[_lib.SCAL_LOSS].to(torch.float32)
-        E = sc[_lib.SCAL_E].to(torch.float32)
-        ctx.mark_non_differentiable(E)
-        return loss, E
 
-    @staticmethod
-    def backward(ctx, gloss, _gE):
-        plan = ctx.plan
-        xh, scc, nv, levels, prior, y, h1c, h2c = ctx.saved_tensors
-        if plan.elbo_generation != ctx.generation:
-            ctx.generation = ElboLossFn._forward_stages(plan, xh, y, h1c, h2c, scc, nv, levels, prior)
-        gs = gloss.detach().to(torch.float32).reshape(1).contiguous()
-        gx = torch.empty_like(xh)
-        plan.sym_bwd(xh, levels, prior, scc, nv, grad_scale=gs, gxhat=gx)
-        s1, s2, s3, sx = ctx.shapes
-        g_h1 = torch.empty(s1, dtype=torch.float32, device=xh.device)
-        g_h2 = torch.empty(s2, dtype=torch.float32, device=xh.device)
-        g_sc = torch.empty(s3, dtype=torch.float32, device=xh.device)
-        plan.finish_grads(3, g_h1=g_h1, g_h2=g_h2, g_scaling=g_sc, grad_scale=gs)
-        return None, gx.view(sx), None, g_h1, g_h2, g_sc, None, None, None
+@torch.library.custom_op("v2vae::equaliser", mutates_args=(), device_types="cuda")
+def _op_equaliser(y: torch.Tensor, k1: torch.Tensor, k2: Optional[torch.Tensor], plan: int) -> torch.Tensor:
+    """xhat [ns, sym_cnt] = equaliser(y [ns, N]; k1, k2) through v2vae_prep_tables + v2vae_eq_fwd."""
+    pl = plan_from_handle(plan)
+    _require_gpu_f32(y, "y")
+    pl.prep_tables(k1=k1.detach().contiguous(), k2=None if k2 is None else k2.detach().contiguous())
+    xhat = torch.empty((pl.p.ns, pl.p.sym_cnt), dtype=torch.float32, device=y.device)
+    pl.eq_fwd(y, xhat)
+    return xhat
+
+
+@_op_equaliser.register_fake
+def _(y, k1, k2, plan):
+    pl = plan_from_handle(plan)
+    return y.new_empty((pl.p.ns, pl.p.sym_cnt), dtype=torch.float32)
+
+
+@torch.library.custom_op("v2vae::equaliser_backward", mutates_args=(), device_types="cuda")
+def _op_equaliser_backward(y: torch.Tensor, gx: torch.Tensor, plan: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(g_k1, g_k2) flat, through v2vae_eq_bwd + v2vae_finish_grads; g_k2 is empty for a first-order equaliser."""
+    pl = plan_from_handle(plan)
+    n = pl.sizes
+    pl.eq_bwd(y, gx.contiguous())
+    g_k1 = torch.empty(n[2], dtype=torch.float32, device=y.device)
+    g_k2 = torch.empty(n[3], dtype=torch.float32, device=y.device)
+    pl.finish_grads(4, g_k1=g_k1, g_k2=g_k2 if n[3] else None)
+    return g_k1, g_k2
+
+
+@_op_equaliser_backward.register_fake
+def _(y, gx, plan):
+    n = plan_from_handle(plan).sizes
+    return y.new_empty(n[2], dtype=torch.float32), y.new_empty(n[3], dtype=torch.float32)
+
+
+def _equaliser_setup(ctx, inputs, output):
+    y, k1, k2, plan = inputs
+    ctx.save_for_backward(y)
+    ctx.plan = plan
+    ctx.k_shapes = (k1.shape, None if k2 is None else k2.shape)
+
+
+def _equaliser_backward(ctx, gx):
+    (y,) = ctx.saved_tensors
+    g_k1, g_k2 = torch.ops.v2vae.equaliser_backward(y, gx, ctx.plan)
+    s1, s2 = ctx.k_shapes
+    return None, g_k1.view(s1), None if s2 is None else g_k2.view(s2), None
+
+
+_op_equaliser.register_autograd(_equaliser_backward, setup_context=_equaliser_setup)
+
+
+def _elbo_stages(pl: Plan, xh, y, snap, levels, prior):
+    n = pl.sizes
+    h1c, h2c, scc, nv = snap[:n[0]], snap[n[0]:n[0] + n[1]], snap[n[0] + n[1]:n[0] + n[1] + n[4]], snap[-1:]
+    pl.prep_tables(h1=h1c, h2=h2c)
+    pl.demap_moments(xh, levels, prior, scc, nv)
+    pl.elbo_fused(y)
+    pl.reduce_scalars()
+    pl.finalize_scalars()
+    return scc, nv
+
+
+@torch.library.custom_op("v2vae::elbo_loss", mutates_args=(), device_types="cuda")
+def _op_elbo_loss(xhat: torch.Tensor, y: torch.Tensor, h1: torch.Tensor, h2: torch.Tensor, scaling: torch.Tensor,
+                  noise_var: torch.Tensor, levels: torch.Tensor, prior: torch.Tensor,
+                  plan: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(loss = KL + W log E, E, snapshot) through the fused ELBO kernels.  `snapshot` = [h1 | h2 | scaling | noise variance] as
+    they were at this call: the backward op works from it, so later in-place updates of the parameters or of the noise
+    variance (lib/real_equalization.py:921-923) do not reach an earlier loss's gradients."""
+    pl = plan_from_handle(plan)
+    _require_gpu_f32(y, "y")
+    snap = torch.cat([h1.detach().reshape(-1), h2.detach().reshape(-1), scaling.detach().reshape(-1),
+                      noise_var.detach().reshape(-1)[:1]])
+    _elbo_stages(pl, xhat.detach().contiguous(), y, snap, levels, prior)
+    sc = pl.scal.clone()
+    return sc[_lib.SCAL_LOSS].to(torch.float32), sc[_lib.SCAL_E].to(torch.float32), snap
+
+
+@_op_elbo_loss.register_fake
+def _(xhat, y, h1, h2, scaling, noise_var, levels, prior, plan):
+    return (xhat.new_empty((), dtype=torch.float32), xhat.new_empty((), dtype=torch.float32),
+            xhat.new_empty(h1.numel() + h2.numel() + scaling.numel() + 1, dtype=torch.float32))
+
+
+@torch.library.custom_op("v2vae::elbo_loss_backward", mutates_args=(), device_types="cuda")
+def _op_elbo_loss_backward(gloss: torch.Tensor, xhat: torch.Tensor, y: torch.Tensor, snap: torch.Tensor, levels: torch.Tensor,
+                           prior: torch.Tensor, plan: int,
+                           restage: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(d loss / d xhat, g_h1, g_h2, g_scaling) flat.  The backward reads dE/d(moments), the partial records and W / E from the
+    plan's workspace; `restage` re-runs the forward stages first (needed if anything else ran on the plan since the forward)."""
+    pl = plan_from_handle(plan)
+    n = pl.sizes
+    xh = xhat.detach().contiguous()
+    if restage:
+        scc, nv = _elbo_stages(pl, xh, y, snap, levels, prior)
+    else:
+        scc, nv = snap[n[0] + n[1]:n[0] + n[1] + n[4]], snap[-1:]
+    gs = gloss.detach().to(torch.float32).reshape(1).contiguous()
+    gx = torch.empty_like(xh)
+    pl.sym_bwd(xh, levels, prior, scc, nv, grad_scale=gs, gxhat=gx)
+    g_h1 = torch.empty(n[0], dtype=torch.float32, device=xh.device)
+    g_h2 = torch.empty(n[1], dtype=torch.float32, device=xh.device)
+    g_sc = torch.empty(n[4], dtype=torch.float32, device=xh.device)
+    pl.finish_grads(3, g_h1=g_h1, g_h2=g_h2, g_scaling=g_sc, grad_scale=gs)
+    return gx, g_h1, g_h2, g_sc
+
+
+@_op_elbo_loss_backward.register_fake
+def _(gloss, xhat, y, snap, levels, prior, plan, restage):
+    n = plan_from_handle(plan).sizes
+    f = lambda k: xhat.new_empty(k, dtype=torch.float32)
+    return torch.empty_like(xhat), f(n[0]), f(n[1]), f(n[4])
+
+
+def _elbo_setup(ctx, inputs, output):
+    xhat, y, h1, h2, scaling, noise_var, levels, prior, plan = inputs
+    ctx.save_for_backward(xhat.detach(), y, output[2], levels, prior)
+    ctx.plan = plan
+    ctx.shapes = (h1.shape, h2.shape, scaling.shape, xhat.shape)
+    ctx.generation = [plan_from_handle(plan).elbo_generation]   # mutable: a re-staging backward brings it up to date
+
+
+def _elbo_backward(ctx, gloss, _gE, _gsnap):
+    xh, y, snap, levels, prior = ctx.saved_tensors
+    pl = plan_from_handle(ctx.plan)
+    restage = pl.elbo_generation != ctx.generation[0]
+    gx, g_h1, g_h2, g_sc = torch.ops.v2vae.elbo_loss_backward(gloss, xh, y, snap, levels, prior, ctx.plan, restage)
+    if restage:
+        ctx.generation[0] = pl.elbo_generation
+    s1, s2, s3, sx = ctx.shapes
+    return gx.view(sx), None, g_h1.view(s1), g_h2.view(s2), g_sc.view(s3), None, None, None, None
+
+
+_op_elbo_loss.register_autograd(_elbo_backward, setup_context=_elbo_setup)
+
+
+def equaliser(plan: Plan, y, k1, k2):
+    """xhat = equaliser(y; k1, k2) as the registered op torch.ops.v2vae.equaliser (differentiable in k1, k2)."""
+    return torch.ops.v2vae.equaliser(y, k1, k2, plan.handle)
+
+
+def elbo_loss(plan: Plan, xhat, y, h1, h2, scaling, noise_var, levels, prior):
+    """(loss, E) as the registered op torch.ops.v2vae.elbo_loss (differentiable in xhat, h1, h2, scaling)."""
+    loss, E, _ = torch.ops.v2vae.elbo_loss(xhat, y, h1, h2, scaling, noise_var, levels, prior, plan.handle)
+    return loss, E.detach()
+
+
+class EqualiserFn:
+    """Kept for callers of the earlier autograd.Function interface: EqualiserFn.apply(plan, y, k1, k2)."""
+    apply = staticmethod(equaliser)
+
+
+class ElboLossFn:
+    """Kept for callers of the earlier autograd.Function interface: ElboLossFn.apply(plan, xhat, y, h1, h2, ...)."""
+    apply = staticmethod(elbo_loss)
