@@ -164,11 +164,16 @@ def main():
     ap.add_argument("--data-source", choices=["host", "device"], default="host",
                     help="host: numpy generator + one H2D copy (default, as in earlier rounds); device: the sequence is produced "
                          "in HBM by v2vae_synth_channel (no host work; meant for the 2^26-symbol configuration)")
-    ap.add_argument("--workload", choices=["train_step", "sweep"], default="train_step",
-                    help="train_step: the headline configuration (default); sweep: 1024 independent real PAM-4 models, L=15")
+    ap.add_argument("--workload", choices=["train_step", "cfg4", "sweep"], default="train_step",
+                    help="train_step: the headline configuration, BASELINE.json configs[1] per GPU (default, at every --gpus N, so "
+                         "that the per-N values form one weak-scaling curve); cfg4: the shape of BASELINE.json configs[3] per GPU "
+                         "(complex 64-QAM, L=65, l1=l2=65, 2^23 symbols per GPU = 2^26 over 8, data generated on the device); "
+                         "sweep: 1024 independent real PAM-4 models, L=15")
     args = ap.parse_args()
     if args.workload == "sweep":
         return sweep_main(args)
+    if args.workload == "cfg4":
+        args.channel_memory, args.lags, args.order, args.log2_symbols, args.data_source = 65, 65, 64, 23, "device"
 
     import torch
     import torch.distributed as dist

@@ -209,6 +209,7 @@ def test_sweep_class_equals_individual_models():
     y_eq, curves = sweep.fit(rxs)
     assert y_eq.shape == (M, nb * B) and curves.shape == (M, nb)
     dec = sweep.decide(rxs)
+    ones = []
     for m in range(M):
         one = SecondVolterraV2VAE(channel_memory=L, learning_rate=5e-3, constellation=const, samples_per_symbol=S, batch_size=B,
                                   noise_variance=nv0[m], torch_device=dev, equaliser_n_lags1=l1, equaliser_n_lags2=l2)
@@ -219,6 +220,14 @@ def test_sweep_class_equals_individual_models():
         assert torch.equal(one._noise_var[0], sweep.noise_variance[m])
         q = one.estimate_symbol_probs(rxs[m])
         assert np.array_equal(q.argmax(axis=0), dec[m])
-    # second call continues optimiser state and schedule position
+        ones.append(one)
+    # A second fit() continues the optimiser state AND the learning-rate decay: the reference builds a new StepLR on the same
+    # optimiser, which starts from the already decayed rate (1 % of the initial one after the first call).
     y2, c2 = sweep.fit(rxs)
     assert np.isfinite(c2).all() and sweep.step_count == 2 * nb
+    assert abs(sweep._current_lr / 5e-3 - 1e-4) < 1e-9
+    for m, one in enumerate(ones):
+        ye, lc = one.fit(rxs[m])
+        assert abs(one.optimizer.param_groups[0]["lr"] - sweep._current_lr) < 1e-12
+        assert np.array_equal(ye, y2[m]) and np.array_equal(lc, c2[m])
+        assert torch.equal(one._pack, sweep.params[m])

@@ -52,6 +52,7 @@ class SecondVolterraV2VAESweep:
         nv = np.broadcast_to(np.asarray(noise_variance, dtype=np.float32), (n_models,)).copy()
         self.noise_variance = torch.from_numpy(nv).to(dev)
         self.step_count = 0
+        self._current_lr = learning_rate   # the optimiser's rate; StepLR decays it in place across fit() calls
 
     # views with the reference's attribute names, leading dimension = model
     @property
@@ -76,14 +77,22 @@ class SecondVolterraV2VAESweep:
         return self.params[:, self._o[4]:self._o[5]]
 
     def _learning_rates(self, n_batches):
+        """One learning rate per batch of this fit() call.  As in the reference, every fit() creates a new StepLR (10 steps
+        down to 1 % over the call, lib/real_equalization.py:476-480) on the SAME optimiser, and a new StepLR starts from the
+        optimiser's current - already decayed - rate, so the rate keeps falling across calls."""
         if not self.lr_schedule:
             return [self.learning_rate] * n_batches
-        # StepLR over one fit() call: 10 steps down to 1 % (lib/real_equalization.py:476-480)
         gamma = np.exp(np.log(0.01) / 10)
         every = n_batches // 10
         if every == 0:
             raise ZeroDivisionError("StepLR needs at least 10 batches per fit (as in the reference)")
-        return [self.learning_rate * gamma ** (n // every) for n in range(n_batches)]
+        lrs, cur = [], self._current_lr
+        for n in range(n_batches):
+            lrs.append(cur)
+            if (n + 1) % every == 0:   # StepLR.step() after batch n: last_epoch = n + 1
+                cur *= gamma
+        self._current_lr = cur
+        return lrs
 
     def fit(self, y_input):
         """y_input: [n_models, N] (one received sequence per model) or [N] (shared).  Returns
