@@ -47,6 +47,8 @@ extern "C" {
 
 #define V2VAE_FLAG_GENERIC 1     /* the generic FMA kernels for every shape (no matrix-core / on-chip kernels) */
 #define V2VAE_FLAG_EQ_MFMA_FWD 2 /* complex, l2 <= 31: the matrix-core forward equaliser instead of the symmetric-form one */
+#define V2VAE_FLAG_ELBO_TILES 4  /* complex, <= 16 active taps per phase: the block-tile matrix-core ELBO kernel (workgroup barriers
+                                    per tile) instead of the run kernel (every wave on its own run of windows) */
 
 typedef struct v2vae_problem {
     int32_t ns;      /* 1 or 2 */
@@ -302,9 +304,9 @@ uint64_t v2vae_synth_bits(uint64_t seed, uint64_t kind, uint64_t idx);
 
 /* Read-only views into the workspace for tests and tooling: float offsets (in floats from the
  * workspace base) of the per-symbol moments [ns][4][sym_cnt] and of dE/d(moments), same shape.
- * When the complex model runs on the matrix-core ELBO kernels, plane 3 of dE/d(moments) (4th cumulant) is
- * filled only for the symbols at the two ends of the sequence; for every other symbol the gradient is one
- * constant that v2vae_sym_bwd takes from the coefficient table. */
+ * Complex model on the matrix-core ELBO kernels: the dE/d(moments) planes are not (<= 16 active taps per phase) or only
+ * partly (longer channels: not plane 3 away from the two ends of the sequence) filled; those kernels hand the per-symbol
+ * backward their gradients in a layout of their own. */
 int64_t v2vae_ws_offset_moments(const v2vae_problem* p);
 int64_t v2vae_ws_offset_gmoments(const v2vae_problem* p);
 

@@ -255,3 +255,23 @@ def test_complex_long_equaliser_blocked_kernel_matches_oracle(l1, l2, S, B):
     assert rel(out["g"]["k1"], tk1.grad) < 2 * TOL
     assert rel(out["g"]["k2"], tk2.grad) < 2 * TOL
     assert rel(out["g"]["h1"], th1.grad) < TOL
+
+
+@pytest.mark.parametrize("L,S,B", [(25, 2, 5000), (25, 2, 331), (16, 1, 2049), (31, 2, 1500), (9, 2, 700)])
+def test_run_and_block_tile_elbo_kernels_agree(L, S, B):
+    """The two matrix-core ELBO kernels of the complex model (every wave on its own run of windows - the default - and the
+    earlier block-tile kernel, V2VAE_FLAG_ELBO_TILES) are different programs for the same sums."""
+    from volterra_vae_amd import _lib
+    from volterra_vae_amd.ops import Plan
+    l1 = l2 = 25
+    M = 4
+    y, levels, prior, scaling, h1, h2, k1, k2 = _complex_inputs(11, L, S, l1, l2, B, M)
+    outs = []
+    for flags in (0, _lib.FLAG_ELBO_TILES):
+        plan = Plan(ns=2, sps=S, l1=l1, pad1=l1 // 2, l2=l2, L=L, C_levels=M, n_glob=B * S, device="cuda", flags=flags)
+        o = run_step(plan, dev(y), dev(h1), dev(h2), dev(k1), dev(k2), dev(levels), dev(prior), dev(scaling), dev(np.array([0.08])))
+        outs.append(dict(E=float(o["E"]), loss=float(o["loss"]), gx=o["gx"].clone(), **{k: v.clone() for k, v in o["g"].items()}))
+    a, b = outs
+    assert abs(a["E"] - b["E"]) < 1e-6 * abs(b["E"]) and abs(a["loss"] - b["loss"]) < 1e-6 * abs(b["loss"])
+    for k in ("gx", "h1", "h2", "k1", "k2", "sc"):
+        assert rel(a[k], b[k].cpu().numpy()) < 2e-6, k

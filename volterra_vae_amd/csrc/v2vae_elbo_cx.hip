@@ -35,6 +35,17 @@ namespace v2vae {
 // The s s^T accumulation is not done here at all: it is a sum of lagged products along the symbol axis
 // (k_psum_cx + psum_value below), O(Le) instead of O(Le^2) per window.
 // ------------------------------------------------------------------------------------------------------------
+// Which (stream, tap) of the H w operand sits on k-slot (step s, lane half h) of the run kernel.  NK = 16: the accumulator
+// layout as it is (steps 0-7 alpha, 8-15 beta, tap cx_kk(s & 7, h)).  NK = 13 (taps 13-15 do not exist): steps 0-4 alpha and
+// 5-9 beta of the slots q = s % 5 (taps 0-3, 8 on the lower half, 4-7, 12 on the upper), steps 10-12: lower half alpha, upper half
+// beta, both of tap 9 + (s - 10), a lower-half tap.
+template <int NK>
+__host__ __device__ __forceinline__ void cx3_hw_slot(int s, int h, int* stream, int* tap) {
+    if (NK == 16) { *stream = s >> 3; *tap = ((s & 7) & 3) + 8 * ((s & 7) >> 2) + 4 * h; }
+    else if (s < 10) { const int q = s % 5; *stream = s / 5; *tap = (q & 3) + 8 * (q >> 2) + 4 * h; }
+    else { *stream = h; *tap = 9 + (s - 10); }
+}
+
 constexpr int CX2_TWB = 256;
 constexpr int CX2_MS = CX2_TWB + 48;
 constexpr int CX2_NU = CX2_TWB / 32;
@@ -437,6 +448,394 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The same mathematics without a workgroup barrier in the main loop: every wave works alone on a RUN of consecutive windows
+// of one phase (the run's symbols [a, b) plus the kmax windows before a, which it recomputes un-owned, exactly as a block tile
+// does above).  A run is cut into strips of CX3_WT windows whose moments the wave stages in its own LDS planes; the per-symbol
+// gradients (symbol = window + tap) are accumulated with LDS float adds into the wave's own per-symbol arrays - one array per
+// lane half, so that no two lanes of one instruction ever meet at an address and the result is bit-reproducible - and carried
+// from strip to strip; a strip's finished symbols go straight to global memory.  With two phases (S = 2) the two waves that cover
+// the same symbols write separate planes (phase 0: the gradient planes proper, phase 1: a second set) and the per-symbol
+// backward adds them, together with the correlation part of the variance gradient.
+// NK = k-steps of the H X and H w products: 16, or 13 when no phase has more than 13 active taps (the k index then runs over
+// [stream][13 taps] and three values of the H w operand change lane halves).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int CX3_WT = 192;                 // windows per strip
+constexpr int CX3_MS = CX3_WT + 32;         // staged symbols per strip (16 used beyond the windows; 32 keeps the gradient
+                                            // update of a slab, 64 lanes wide, inside the arrays)
+constexpr int CX3_NW = 8;                   // waves per workgroup
+constexpr int CX3_ADB = 16 * 32 + 4;        // 4-vectors of the anti-diagonal buffer (16 tap rows of 32 windows + a zero vector)
+// floats of one wave's private LDS: 7 moment planes, the per-symbol gradient 4-vectors, the anti-diagonal buffer (which the
+// transposing buffer of the rho / sigma rows shares: the two are used one after the other within a slab)
+constexpr int CX3_WAVE_F = 7 * CX3_MS + 4 * CX3_MS + 4 * CX3_ADB;
+
+__host__ __device__ constexpr int cx3_lds_floats(int S, int NK) {
+    return S * 2 * NK * 64 + S * 64 + CX3_NW * CX3_WAVE_F;
+}
+
+template <int S, int NK>
+__global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __restrict__ y, float* __restrict__ ws) {
+    extern __shared__ __align__(16) float sm[];
+    constexpr int WT = CX3_WT, MS = CX3_MS, TP = CX_TP, NW = CX3_NW;
+    constexpr int NWP = NW / S;
+    constexpr int CX3_NT = NW * 64;
+    static_assert(NK == 16 || NK == 13, "k-step counts with an operand schedule");
+    float* s_A = sm;                           // [S][2 NK][64]  A operands: steps 0..NK-1 H X, NK..2NK-1 H w
+    float* s_c = s_A + S * 2 * NK * 64;        // [S][4][16]     h1r, h1i, diag Hr, diag Hi
+    float* s_W = s_c + S * 64;                 // [NW][CX3_WAVE_F]
+    __shared__ double dred[CX3_NT / 64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int r = wv / NWP, wsub = wv % NWP;
+    float* stg = s_W + wv * CX3_WAVE_F;        // [7][MS]
+    f32x4* G4 = reinterpret_cast<f32x4*>(stg + 7 * MS);   // [MS] per-symbol gradients (d/d mean_a, mean_b, var_a, var_b) of the strip
+    f32x4* Bd = G4 + MS;                       // [ADB] anti-diagonal buffer
+    float* Tb = reinterpret_cast<float*>(Bd);  // [32 * TP] transposing buffer of rho / sigma, in the same memory
+    static_assert(32 * CX_TP <= 4 * CX3_ADB && S * CX_REC <= CX3_WAVE_F, "shared regions");
+    const float* __restrict__ mom = ws + l.o_mom;
+    const int64_t own_hi = l.own_lo + l.own_cnt, sym_hi = l.sym_lo + l.sym_cnt, st = l.sym_cnt;
+    const int cj = i >> 4, yj = i & 15;
+
+    // ---- constants of every phase into LDS
+    for (int idx = tid; idx < S * 2 * NK * 64; idx += CX3_NT) {
+        const int ln = idx & 63, s = (idx >> 6) % (2 * NK), rr = idx / (2 * NK * 64);
+        const int jj = ln & 31, hh = ln >> 5, cjj = jj >> 4, yjj = jj & 15;
+        const float* Hr = ws + l.o_cxH + (size_t)(rr * 2 + 0) * 256;
+        const float* Hi = ws + l.o_cxH + (size_t)(rr * 2 + 1) * 256;
+        float v;
+        if (s < NK) {          // [[Hr, Hi], [-Hi, Hr]], row k = 2 s + h over [stream][NK taps]
+            const int k = 2 * s + hh, ck = k / NK, xk = k - ck * NK;
+            float a = Hr[xk * 16 + yjj], b = Hi[xk * 16 + yjj];
+            // NK = 13: output row 13 (no such tap) computes the first-order term h1 . X of the window instead
+            if (NK == 13 && yjj == 13) { a = ws[l.o_cxh1 + (rr * 2 + 0) * 16 + xk]; b = ws[l.o_cxh1 + (rr * 2 + 1) * 16 + xk]; }
+            v = ck == 0 ? (cjj == 0 ? a : b) : (cjj == 0 ? -b : a);
+        } else {               // [[Hr, -Hi], [Hi, Hr]], row = the (stream, tap) that cx3_hw_slot puts on k-slot (s - NK, h)
+            int ck, xk;
+            cx3_hw_slot<NK>(s - NK, hh, &ck, &xk);
+            const float a = Hr[xk * 16 + yjj], b = Hi[xk * 16 + yjj];
+            v = ck == 0 ? (cjj == 0 ? a : -b) : (cjj == 0 ? b : a);
+        }
+        s_A[idx] = v;
+    }
+    for (int idx = tid; idx < S * 64; idx += CX3_NT) {
+        const int rr = idx / 64, q = (idx >> 4) & 3, x = idx & 15;
+        const float* Hr = ws + l.o_cxH + (size_t)(rr * 2 + 0) * 256;
+        const float* Hi = ws + l.o_cxH + (size_t)(rr * 2 + 1) * 256;
+        s_c[idx] = q == 0 ? ws[l.o_cxh1 + (rr * 2 + 0) * 16 + x] : q == 1 ? ws[l.o_cxh1 + (rr * 2 + 1) * 16 + x]
+                 : q == 2 ? Hr[x * 16 + x] : Hi[x * 16 + x];
+    }
+    const float* Aop = s_A + (size_t)r * 2 * NK * 64 + lane;
+    const float* cst = s_c + r * 64 + 4 * h;
+    __syncthreads();
+
+#ifdef V2VAE_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+#endif
+    f32x16 R;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) R[g] = 0.f;
+    f2 ghr[4], ghi[4], gdr[4], gdi[4];  // vector gradients of the tap pairs (2 p, 2 p + 1)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { ghr[p] = 0.f; ghi[p] = 0.f; gdr[p] = 0.f; gdi[p] = 0.f; }
+    double Eacc = 0.0;
+
+    // ---- this wave's run: symbols [a, b) of phase r
+    const int64_t run = (int64_t)blockIdx.x * NWP + wsub;
+    const int64_t a = l.own_lo + run * l.cx_rl;
+    const int64_t b = (a + l.cx_rl < own_hi) ? a + l.cx_rl : own_hi;
+    // this phase's array of per-symbol 4-vectors (gradients of mean_a, mean_b, var_a, var_b)
+    f32x4* __restrict__ gout = reinterpret_cast<f32x4*>(ws + l.o_gpk) + (int64_t)r * st;
+
+    auto load_y = [&](int64_t t, int o) -> float {
+        const int64_t n = t * S + r;
+        float v = 0.f;
+        if (t < b && n >= 0 && n < l.W) {
+            const int64_t loc = l.pre + n - l.y_lo;
+            if (loc >= 0 && loc < l.y_len) v = y[(int64_t)o * l.y_stride + loc];
+        }
+        return v;
+    };
+
+    // Moments travel from global memory to the wave's planes 32 symbols at a time, one slab ahead of their use: lane (j, g) holds
+    // the four moments of stream g of symbol j of the group; the sums / differences across the streams are formed on the way in.
+    float pm[4];
+    auto fetch32 = [&](int64_t m0) {
+        const int64_t m = m0 + i;
+        pm[0] = 0.f; pm[1] = 0.f; pm[2] = 0.f; pm[3] = 0.f;
+        if (m >= l.sym_lo && m < sym_hi) {
+            const float* g = mom + (int64_t)h * 4 * st + (m - l.sym_lo);
+            pm[0] = g[0]; pm[1] = g[st]; pm[2] = g[2 * st]; pm[3] = g[3 * st];
+        }
+    };
+    auto store32 = [&](int e0, int jmin) {   // members j >= jmin of the held group become staged symbols e0 + j
+        const float ov = __shfl_xor(pm[1], 32), og = __shfl_xor(pm[3], 32);
+        float* d = stg + e0 + i;
+        if (i >= jmin) {
+            d[h * MS] = pm[0];                                  // mean_a | mean_b
+            d[(2 + h) * MS] = h ? ov - pm[1] : pm[1] + ov;      // v_a + v_b | v_a - v_b
+            d[(4 + h) * MS] = pm[2];                            // 3rd central moments
+            if (h == 0) d[6 * MS] = pm[3] + og;                 // g_a + g_b
+        }
+    };
+
+    bool first = true;
+    for (int64_t ts = a - l.kmax; a < own_hi && ts < b; ts += WT, first = false) {
+        const int64_t left = b - ts;
+        const int nsl = left >= WT ? WT / 32 : (int)((left + 31) / 32);   // slabs of this strip
+        // ---- per-symbol gradients: keep what the previous strip left for this strip's first 16 symbols, clear the rest;
+        //      the last 16 staged symbols of the previous strip are this strip's first 16
+        {
+            f32x4 carry = {0.f, 0.f, 0.f, 0.f};
+            float c0 = 0.f, c1 = 0.f;
+            if (!first) {
+                if (lane < 16) carry = G4[WT + lane];
+                c0 = stg[(lane >> 4) * MS + WT + (lane & 15)];
+                if (lane < 48) c1 = stg[(4 + (lane >> 4)) * MS + WT + (lane & 15)];
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int e = lane; e < MS; e += 64) G4[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 16) G4[lane] = carry;
+            Bd[16 * 32] = f32x4{0.f, 0.f, 0.f, 0.f};   // the zero vector (the transposing buffer overwrites nothing beyond 32 * TP floats)
+            if (first) {   // start of the run: symbols [ts, ts + 16) directly, the first group of 32 into the registers
+                fetch32(ts - 16);
+                store32(-16, 16);
+            } else {
+                stg[(lane >> 4) * MS + (lane & 15)] = c0;
+                if (lane < 48) stg[(4 + (lane >> 4)) * MS + (lane & 15)] = c1;
+            }
+        }
+        if (first) fetch32(ts + 16);
+        __builtin_amdgcn_wave_barrier();
+        const float* s_mu = stg;
+        const float* s_S = stg + 2 * MS;
+        const float* s_dv = stg + 3 * MS;
+        const float* s_ka = stg + 4 * MS;
+        const float* s_kb = stg + 5 * MS;
+        const float* s_gs = stg + 6 * MS;
+        float yn0 = load_y(ts + i, 0), yn1 = load_y(ts + i, 1);
+        STAMP(0);
+
+        for (int sub = 0; sub < nsl; ++sub) {
+            const int tsl = sub * 32;
+            const int64_t t = ts + tsl + i, n = t * S + r;
+            const bool valid = (t < b) && n >= 0 && n < l.W;
+            const bool own = valid && t >= a;
+            const float mv = valid ? 1.f : 0.f, mo = own ? 1.f : 0.f;
+            const float y0 = yn0, y1 = yn1;
+            if (sub + 1 < nsl) { yn0 = load_y(t + 32, 0); yn1 = load_y(t + 32, 1); }
+            store32(tsl + 16, 0);                    // symbols [tsl + 16, tsl + 48) complete what this slab reads
+            fetch32(ts + tsl + 48);                  // the group the next slab (of this or of the next strip) will add
+            __builtin_amdgcn_wave_barrier();
+
+            f32x16 U;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) U[g] = 0.f;
+#pragma unroll
+            for (int s = 0; s < NK; ++s) {
+                // k = 2 s + h over [stream][NK taps]
+                int off;
+                if (2 * s + 1 < NK) off = 2 * s + h;
+                else if (2 * s >= NK) off = MS + 2 * s - NK + h;
+                else off = h ? MS : NK - 1;
+                U = MFMA32(Aop[s * 64], s_mu[tsl + i + off], U);
+            }
+
+            STAMP(1);
+            // NK = 13: rows 13 of the product (upper lane half, accumulator slots 5 and 13) hold the first-order term of the window
+            float a0 = 0.f, a1 = 0.f;
+            if (NK == 13) {
+                a0 = h ? U[5] : 0.f; a1 = h ? U[13] : 0.f;
+                U[5] = h ? 0.f : U[5]; U[13] = h ? 0.f : U[13];
+            }
+            // per-tap algebra on tap PAIRS (2 p, 2 p + 1)
+            f2 zP[4], zQ[4], al[4], be[4], zz[4], dvv[4];
+            f2 a0v = 0.f, a1v = 0.f, q0v = 0.f, q1v = 0.f, sd0v = 0.f, sd1v = 0.f, vsv = 0.f;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int slot = tsl + i + cx_kk(2 * p, h);
+                const f2 P = f2{U[2 * p], U[2 * p + 1]}, Q = f2{U[2 * p + 8], U[2 * p + 9]};
+                const f2 ma = ld2(s_mu + slot), mb = ld2(s_mu + MS + slot), Sv = ld2(s_S + slot), dv = ld2(s_dv + slot);
+                const f2 ka = ld2(s_ka + slot), kb = ld2(s_kb + slot), gs = ld2(s_gs + slot);
+                const f2 hr = C2(0, p), hi = C2(1, p), dr = C2(2, p), di = C2(3, p);
+                const f2 zp = 2.f * P + hr, zq = 2.f * Q + hi;
+                if (NK != 13) {
+                    a0v += hr * ma - hi * mb;
+                    a1v += hi * ma + hr * mb;
+                }
+                q0v += ma * P - mb * Q;
+                q1v += ma * Q + mb * P;
+                sd0v += dv * dr;
+                sd1v += dv * di;
+                const f2 z2 = zp * zp + zq * zq;
+                const f2 ca = dr * zp + di * zq, cb = dr * zq - di * zp;
+                vsv += Sv * z2 + 2.f * (ka * ca + kb * cb) + gs * (dr * dr + di * di);
+                al[p] = 2.f * (Sv * zp + ka * dr - kb * di);
+                be[p] = 2.f * (Sv * zq + ka * di + kb * dr);
+                zP[p] = zp; zQ[p] = zq;
+                zz[p] = z2;
+                dvv[p] = dv;
+                gdr[p] += (2.f * mo) * (ka * zp + kb * zq + gs * dr);
+                gdi[p] += (2.f * mo) * (ka * zq - kb * zp + gs * di);
+            }
+            if (NK != 13) { a0 = a0v.x + a0v.y; a1 = a1v.x + a1v.y; }
+            float q0 = q0v.x + q0v.y, q1 = q1v.x + q1v.y;
+            float sd0 = sd0v.x + sd0v.y, sd1 = sd1v.x + sd1v.y, vs = vsv.x + vsv.y;
+            a0 += __shfl_xor(a0, 32); a1 += __shfl_xor(a1, 32);
+            q0 += __shfl_xor(q0, 32); q1 += __shfl_xor(q1, 32);
+            sd0 += __shfl_xor(sd0, 32); sd1 += __shfl_xor(sd1, 32);
+            vs += __shfl_xor(vs, 32);
+            float e0 = a0 + q0 + sd0 - y0, e1 = a1 + q1 + sd1 - y1;
+            if (own && h == 0) Eacc += (double)(e0 * e0 + e1 * e1 + vs);
+            e0 *= mv; e1 *= mv;
+
+            STAMP(2);
+            // ---- H w: k-slot (s, h) carries the (stream, tap) of cx3_hw_slot
+            f32x16 HW;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) HW[g] = 0.f;
+            if (NK == 16) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s)
+                    HW = MFMA32(Aop[(NK + s) * 64], s < 8 ? al[(s & 7) >> 1][s & 1] : be[(s & 7) >> 1][s & 1], HW);
+            } else {
+                // accumulator slots q = 0..4 of either lane half hold valid taps (0-3, 8 | 4-7, 12): ten steps take them as they
+                // are; taps 9, 10, 11 (slots 5-7 of the lower half, whose upper-half partners 13-15 do not exist) take three
+                // steps in which the upper half supplies the lower half's beta value, moved over by a lane-half swap
+#pragma unroll
+                for (int s = 0; s < 5; ++s) HW = MFMA32(Aop[(NK + s) * 64], al[s >> 1][s & 1], HW);
+#pragma unroll
+                for (int s = 0; s < 5; ++s) HW = MFMA32(Aop[(NK + 5 + s) * 64], be[s >> 1][s & 1], HW);
+#pragma unroll
+                for (int s = 5; s < 8; ++s) {
+                    float x = al[s >> 1][s & 1], z = be[s >> 1][s & 1];
+                    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(z));   // x = (alpha of lanes 0-31 | beta of lanes 0-31)
+                    HW = MFMA32(Aop[(NK + 5 + s) * 64], x, HW);
+                }
+            }
+
+            STAMP(3);
+            // ---- gradients of the means and variances of symbol (window + tap): anti-diagonal sums of the slab through the
+            //      wave's zero-padded buffer of 4-vectors, then one update of the strip's per-symbol array (47 symbols)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int x = cx_kk(2 * p, h);
+                const f2 zp = zP[p], zq = zQ[p], dr = C2(2, p), di = C2(3, p);
+                const f2 ed = 2.f * (e0 * dr + e1 * di);
+                const f2 da0 = (2.f * mv) * (e0 * zp + e1 * zq + f2{HW[2 * p], HW[2 * p + 1]});
+                const f2 db0 = (2.f * mv) * (e1 * zp - e0 * zq + f2{HW[2 * p + 8], HW[2 * p + 9]});
+                const f2 da1 = mv * (zz[p] + ed), db1 = mv * (zz[p] - ed);
+                Bd[x * 32 + i] = f32x4{da0.x, db0.x, da1.x, db1.x};
+                Bd[(x + 1) * 32 + i] = f32x4{da0.y, db0.y, da1.y, db1.y};
+            }
+            __builtin_amdgcn_wave_barrier();
+            {
+                f32x4 sv = G4[tsl + lane];
+#pragma unroll
+                for (int x = 0; x < 16; ++x)   // row x, window lane - x (the zero vector when that is not a window of the slab)
+                    sv += Bd[(unsigned)(lane - x) < 32u ? x * 31 + lane : 16 * 32];
+                G4[tsl + lane] = sv;
+            }
+            __builtin_amdgcn_wave_barrier();
+
+            STAMP(4);
+            // ---- rho / sigma (transposed through LDS), vector gradients
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int x = cx_kk(2 * p, h);
+                const int slot = tsl + i + x;
+                const f2 ma = ld2(s_mu + slot), mb = ld2(s_mu + MS + slot);
+                const f2 gr = 2.f * (e0 * ma + e1 * mb), gi = 2.f * (e1 * ma - e0 * mb);
+                ghr[p] += mo * (gr + al[p]);
+                ghi[p] += mo * (gi + be[p]);
+                gdr[p] += (mo * 2.f * e0) * dvv[p];
+                gdi[p] += (mo * 2.f * e1) * dvv[p];
+                const f2 t0 = mo * (gr + 2.f * al[p]), t1 = mo * (gi + 2.f * be[p]);
+                Tb[i * TP + x] = t0.x;
+                Tb[i * TP + x + 1] = t0.y;
+                Tb[i * TP + 16 + x] = t1.x;
+                Tb[i * TP + 16 + x + 1] = t1.y;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int w = 2 * s + h;
+                R = MFMA32(Tb[w * TP + i], s_mu[cj * MS + tsl + w + yj], R);
+            }
+            __builtin_amdgcn_wave_barrier();
+            STAMP(5);
+        }
+
+        // ---- the strip's finished symbols (every window that holds them has been processed) go to global memory
+        {
+            const int64_t lo = ts > a ? ts : a;
+            const int64_t hi2 = ts + nsl * 32 < b ? ts + nsl * 32 : b;
+            for (int e = lane; e < nsl * 32; e += 64) {
+                const int64_t m = ts + e;
+                if (m >= lo && m < hi2) gout[m - l.sym_lo] = G4[e];
+            }
+        }
+        STAMP(6);
+        __builtin_amdgcn_wave_barrier();
+    }
+
+#ifdef V2VAE_STAMPS
+    if (lane == 0) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(ws + l.o_sumstage);  // free until the record sums run
+        for (int k = 0; k < 8; ++k) dbg[((size_t)blockIdx.x * NW + wv) * 8 + k] = st_acc[k];
+    }
+#endif
+    // ---- one record per (block, phase); Ps block of the record is left zero (filled from the lagged sums later)
+    __syncthreads();
+    float* img = s_W + (size_t)r * CX_REC;  // wave 0's private area holds the S records (every wave is past its run here)
+    float vsum[8][4];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        float v0 = ghr[q >> 1][q & 1], v1 = ghi[q >> 1][q & 1], v2 = gdr[q >> 1][q & 1], v3 = gdi[q >> 1][q & 1];
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) {
+            v0 += __shfl_xor(v0, off); v1 += __shfl_xor(v1, off);
+            v2 += __shfl_xor(v2, off); v3 += __shfl_xor(v3, off);
+        }
+        vsum[q][0] = v0; vsum[q][1] = v1; vsum[q][2] = v2; vsum[q][3] = v3;
+    }
+    for (int w = 0; w < NWP; ++w) {
+        if (wsub == w) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int e = ((g & 3) + 8 * (g >> 2) + 4 * h) * 32 + i;
+                if (w == 0) { img[e] = R[g]; img[1024 + e] = 0.f; }
+                else img[e] += R[g];
+            }
+            if (i == 0) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int x = cx_kk(q, h);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        if (w == 0) img[2048 + v * 16 + x] = vsum[q][v];
+                        else img[2048 + v * 16 + x] += vsum[q][v];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float* rec = ws + l.o_part_cx + (size_t)blockIdx.x * S * CX_REC;
+    for (int e = tid; e < S * CX_REC; e += CX3_NT) rec[e] = s_W[e];
+    double v = Eacc;
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();
+    if (lane == 0) dred[wv] = v;
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int w = 0; w < CX3_NT / 64; ++w) s += dred[w];
+        reinterpret_cast<double*>(ws + l.o_Epart)[blockIdx.x] = s;
+    }
+}
+
 constexpr int PS_PER = 8;               // symbols per thread and tile
 constexpr int PS_TILE = NT * PS_PER;    // symbols per tile; the tile's s values plus NLAG of halo are staged in LDS
 
@@ -591,10 +990,16 @@ __global__ __launch_bounds__(NT, 5) void k_g2_cx(Lay l, float* __restrict__ ws) 
             const int64_t m = m0 + i;
             // every window that holds this symbol exists: (m - kmax) * S >= 0 and m * S + S - 1 < W
             if (m < own_hi && m >= l.kmax && m * S + S - 1 < l.W) {
-                float* gp = gmom + (m - l.sym_lo);
-                gp[2 * st] = fmaf(4.f, s_out[0][i & 3][i >> 2], k0r);
-                gp[6 * st] = fmaf(4.f, s_out[1][i & 3][i >> 2], k0i);
-                ws[l.o_gT + (m - l.sym_lo)] = 4.f * s_out[2][i & 3][i >> 2];
+                const float gka = fmaf(4.f, s_out[0][i & 3][i >> 2], k0r), gkb = fmaf(4.f, s_out[1][i & 3][i >> 2], k0i);
+                const float gt = 4.f * s_out[2][i & 3][i >> 2];
+                if (l.cx_split) {
+                    reinterpret_cast<f32x4*>(ws + l.o_gpk)[2 * st + (m - l.sym_lo)] = f32x4{gka, gkb, gt, s_cf[2]};
+                } else {
+                    float* gp = gmom + (m - l.sym_lo);
+                    gp[2 * st] = gka;
+                    gp[6 * st] = gkb;
+                    ws[l.o_gT + (m - l.sym_lo)] = gt;
+                }
             }
         }
     }
@@ -646,9 +1051,13 @@ __global__ __launch_bounds__(NT, 5) void k_g2_cx(Lay l, float* __restrict__ ws) 
         if (threadIdx.x == 0) {
             float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
             for (int w = 0; w < NT / 64; ++w) { a += s_e[w][0]; b += s_e[w][1]; c += s_e[w][2]; d += s_e[w][3]; }
-            float* gp = gmom + (m - l.sym_lo);
-            gp[2 * st] = a; gp[6 * st] = b; gp[3 * st] = c; gp[7 * st] = c;
-            ws[l.o_gT + (m - l.sym_lo)] = d;
+            if (l.cx_split) {
+                reinterpret_cast<f32x4*>(ws + l.o_gpk)[2 * st + (m - l.sym_lo)] = f32x4{a, b, d, c};
+            } else {
+                float* gp = gmom + (m - l.sym_lo);
+                gp[2 * st] = a; gp[6 * st] = b; gp[3 * st] = c; gp[7 * st] = c;
+                ws[l.o_gT + (m - l.sym_lo)] = d;
+            }
         }
     }
 }
@@ -717,19 +1126,23 @@ __global__ __launch_bounds__(NT) void k_chain_channel_cx(Lay l, const float* __r
     }
 }
 
-int launch_elbo_cx(const Lay& l, const float* y, float* ws, hipStream_t st) {
-    const int lds = l.lds_cx;
-#define V2VAE_LAUNCH_CX2(SS)                                                                                               \
-    do {                                                                                                                   \
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_elbo_cx2<SS, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                lds) != hipSuccess)                                                                        \
-            return V2VAE_ELAUNCH;                                                                                          \
-        hipLaunchKernelGGL((k_elbo_cx2<SS, 8>), dim3(l.nblk_cx), dim3(8 * 64), lds, st, l, y, ws);                          \
-    } while (0)
-    if (l.S == 1) V2VAE_LAUNCH_CX2(1);
-    else V2VAE_LAUNCH_CX2(2);
-#undef V2VAE_LAUNCH_CX2
+template <typename K>
+static int launch_cx(K kernel, const Lay& l, int lds, const float* y, float* ws, hipStream_t st) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        return V2VAE_ELAUNCH;
+    hipLaunchKernelGGL(kernel, dim3(l.nblk_cx), dim3(8 * 64), lds, st, l, y, ws);
     return V2VAE_OK;
+}
+
+int launch_elbo_cx(const Lay& l, const float* y, float* ws, hipStream_t st) {
+    if (!l.cx_split) {   // the block-tile kernel (V2VAE_FLAG_ELBO_TILES)
+        if (l.S == 1) return launch_cx(k_elbo_cx2<1, 8>, l, l.lds_cx, y, ws, st);
+        return launch_cx(k_elbo_cx2<2, 8>, l, l.lds_cx, y, ws, st);
+    }
+    const bool k13 = l.LE <= 13;
+    const int lds = cx3_lds_floats(l.S, k13 ? 13 : 16) * 4;
+    if (l.S == 1) return k13 ? launch_cx(k_elbo_cx3<1, 13>, l, lds, y, ws, st) : launch_cx(k_elbo_cx3<1, 16>, l, lds, y, ws, st);
+    return k13 ? launch_cx(k_elbo_cx3<2, 13>, l, lds, y, ws, st) : launch_cx(k_elbo_cx3<2, 16>, l, lds, y, ws, st);
 }
 
 // what needs only the moments and runs right after the soft demapper: lagged products of s = v_a + v_b, and the gradients

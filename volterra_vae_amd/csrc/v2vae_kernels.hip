@@ -25,7 +25,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     if (!p || !out) return V2VAE_EINVAL;
     Lay l{};
     l.ns = p->ns; l.S = p->sps;
-    if (p->flags & ~(V2VAE_FLAG_GENERIC | V2VAE_FLAG_EQ_MFMA_FWD) || p->reserved != 0) return V2VAE_EINVAL;
+    if (p->flags & ~(V2VAE_FLAG_GENERIC | V2VAE_FLAG_EQ_MFMA_FWD | V2VAE_FLAG_ELBO_TILES) || p->reserved != 0) return V2VAE_EINVAL;
     l.flags = p->flags;
     if (p->mode < 0 || p->mode > 3) return V2VAE_EINVAL;
     l.chan = p->mode >= 2 ? p->mode - 1 : 0;  // modes 2, 3: real path with a polynomial channel model
@@ -137,10 +137,20 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     }
     // ---- matrix-core ELBO path: complex model, <= 16 active taps per stream and phase, S in {1, 2}
     l.use_cx = (l.mode == 1 && l.LE <= 16 && l.S <= 2 && !(l.flags & V2VAE_FLAG_GENERIC)) ? 1 : 0;
+    l.cx_split = (l.use_cx && !(l.flags & V2VAE_FLAG_ELBO_TILES)) ? 1 : 0;
     {
         const int ts = 256 - l.kmax;
         l.ntile_cx = (int)((l.own_cnt + ts - 1) / ts);
         l.nblk_cx = l.ntile_cx < CX_BLOCKS ? l.ntile_cx : CX_BLOCKS;
+        if (l.cx_split) {
+            // runs: CX_BLOCKS workgroups x (8 / S) waves per phase; a run is a multiple of 32 symbols
+            const int nwp = 8 / l.S;
+            int64_t rl = (l.own_cnt + (int64_t)CX_BLOCKS * nwp - 1) / ((int64_t)CX_BLOCKS * nwp);
+            rl = rup(rl < 64 ? 64 : rl, 32);
+            l.cx_rl = rl;
+            const int64_t nruns = (l.own_cnt + rl - 1) / rl;
+            l.nblk_cx = (int)((nruns + nwp - 1) / nwp);
+        }
         l.lds_cx = ((7 * (256 + 48) + 2 * l.S * 256) + l.S * 40 * 64 + l.S * 64 + 8 * 32 * CX_TP + 8 * 4 * (16 * 32 + 4) + l.S * 8 * 4 * 64) * 4;
         // blocked variant for longer channels
         l.use_cxb = (l.mode == 1 && l.LE > 16 && l.LE <= 48 && l.S <= 2 && !(l.flags & V2VAE_FLAG_GENERIC)) ? 1 : 0;
@@ -204,6 +214,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     l.o_xlo = take(l.xlo ? l.sym_cnt : 0);
     l.o_mom = take((int64_t)l.ns * 4 * l.sym_cnt);
     l.o_gmom = take((int64_t)l.ns * 4 * l.sym_cnt);
+    l.o_gpk = take(l.cx_split ? 12 * l.sym_cnt : 0);
     l.o_part_elbo = take((int64_t)l.nblk_elbo * l.rec_elbo);
     l.o_part_eq = take((int64_t)l.nblk_eq * l.rec_eq);
     l.o_part_sym = take((int64_t)l.nblk_sym * l.rec_sym);
@@ -662,11 +673,21 @@ __device__ __forceinline__ void d_sym_bwd(const GridCtx gc, Lay l, const float* 
             if (own && c < l.ns) {
                 nx[c] = xhat[(int64_t)c * l.sym_cnt + i];
                 const float* g = gmom + (int64_t)c * 4 * l.sym_cnt + i;
+                if (l.cx_split) continue;
                 ng[c][0] = g[0]; ng[c][1] = g[l.sym_cnt]; ng[c][2] = g[2 * l.sym_cnt];
-                // matrix-core ELBO path: the 4th-cumulant gradient of a symbol all of whose windows exist is one constant
+                // blocked matrix-core ELBO path: the 4th-cumulant gradient of a symbol all of whose windows exist is one constant
                 // (kept in the coefficient table); only the symbols at the ends of the sequence have it in the plane
                 ng[c][3] = (cx_path && b >= l.kmax && b * l.S + l.S - 1 < l.W) ? g4c : g[3 * l.sym_cnt];
             }
+        }
+        if (own && l.cx_split) {   // run kernel: three per-symbol 4-vectors (phase 0, phase 1, k_g2_cx)
+            typedef float v4 __attribute__((ext_vector_type(4)));
+            const v4* pk = reinterpret_cast<const v4*>(ws + l.o_gpk) + i;
+            v4 p0 = pk[0];
+            const v4 p2 = pk[2 * l.sym_cnt];
+            if (l.S == 2) p0 += pk[l.sym_cnt];
+            ng[0][0] = p0.x; ng[0][1] = p0.z + p2.z; ng[0][2] = p2.x; ng[0][3] = p2.w;
+            ng[1][0] = p0.y; ng[1][1] = p0.w + p2.z; ng[1][2] = p2.y; ng[1][3] = p2.w;
         }
     };
     const int64_t stride = (int64_t)gc.nb * NT;
@@ -2102,6 +2123,7 @@ int v2vae_fit_persistent(const v2vae_problem* p, const v2vae_fit_args* a, void* 
     }
     if (!l.generic_elbo_ok || l.maxi_elbo != 1 || l.maxi_eq > 2) return V2VAE_ESIZE;
     l.use_cx = 0;
+    l.cx_split = 0;
     l.use_cxb = 0;
     l.use_eqcx = 0;
     l.use_eqcxb = 0;

@@ -65,6 +65,12 @@ struct Lay {
     int64_t o_psv;  // [S][LE][LE] lagged sums of v_a + v_b per (phase, tap, tap) over the owned windows (k_g2_cx; read by the chain rule)
     int64_t o_gT;   // [sym_cnt] the part of dE/dv (same for both streams) that is a correlation of v_a + v_b (matrix-core ELBO kernels)
     int64_t o_cxH, o_cxh1, o_part_cx, o_tot_cx;
+    // run kernel (k_elbo_cx3): cx_split = 1, every wave owns a run of cx_rl symbols of one phase.  dE/d(moments) then lives in
+    // three arrays of per-symbol 4-vectors at o_gpk, [3][sym_cnt][4]: [0] and [1] the gradients of (mean_a, mean_b, var_a, var_b)
+    // from the windows of phase 0 and of phase 1 (S = 2), [2] = (3rd-moment gradients a, b; the part of the variance gradient
+    // that is a correlation of v_a + v_b; the 4th-cumulant gradient) from k_g2_cx; the per-symbol backward adds them up
+    int cx_split;
+    int64_t cx_rl, o_gpk;
     // blocked matrix-core ELBO path (complex, 16 < active taps per phase <= 48): taps in blocks of 16
     int use_cxb, cxb_nb, cxb_leb, ntile_cxb, nblk_cxb, lds_cxb, cxb_rec;
     int64_t o_cxbA, o_cxbH, o_cxbc, o_part_cxb, o_tot_cxb;
