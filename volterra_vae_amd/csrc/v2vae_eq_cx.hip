@@ -6,8 +6,8 @@
 //
 // Backward: with rho = g0 Ya + g1 Yb, sigma = g1 Ya - g0 Yb (g = dloss/dxhat) the gradient planes are
 // dK_r = sum rho^T Ya + sigma^T Yb and dK_i = sum sigma^T Ya - rho^T Yb, both symmetric in the lag pair: the three
-// upper-triangular 16x16 blocks of each plane per wave, two 16x16x4 MFMAs into each per k-step, four symbols per k-step; a ones column at index l2 of the Ya operand (zero in the Yb operand) yields
-// the first-order gradient in the same products.
+// upper-triangular 16x16 blocks per wave, as three real products each (see the kernel), 16x16x4 MFMAs, four symbols per k-step; a
+// ones column at index l2 of the Ya operand (zero in the Yb operand) yields the first-order gradient in the same products.
 //
 // Applies when mode = complex, l2 odd <= 31, l1 odd <= l2 and pad1 = l1 / 2.
 #include <hip/hip_runtime.h>
@@ -42,9 +42,15 @@ __global__ __launch_bounds__(NT, 4) void k_eq_bwd_cx(Lay l, const float* __restr
     const int i16 = lane & 15, kq = lane >> 4;
     // Both gradient planes are symmetric in the lag pair, so of the 2 x 2 blocks of 16 lags only (0,0), (0,1), (1,1) are
     // accumulated (16x16x4 MFMAs, four symbols per k-step); the chain rule reads block (1,0) from (0,1).
-    f32x4 Rr00, Rr01, Rr11, Ri00, Ri01, Ri11;
+    // The complex accumulation dK_r + i dK_i = sum (rho + i sigma)^T (Ya - i Yb) is formed from THREE real products per block
+    // instead of four:  K1 = (rho + sigma)^T Ya,  K2 = -rho^T (Ya + Yb),  K3 = sigma^T (Ya - Yb);  dK_r = K1 - K3, dK_i = K1 + K2.
+    // The sums are linear, so K1, K2, K3 are accumulated over all symbols and combined once at the end: 9 MFMAs per k-step
+    // instead of 12.  The ones column (first-order gradient) sits in Ya only; its Yb entry is zero in all three operands.
+    f32x4 A00, A01, A11, B00, B01, B11, C00, C01, C11;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) { Rr00[g] = 0.f; Rr01[g] = 0.f; Rr11[g] = 0.f; Ri00[g] = 0.f; Ri01[g] = 0.f; Ri11[g] = 0.f; }
+    for (int g = 0; g < 4; ++g) {
+        A00[g] = 0.f; A01[g] = 0.f; A11[g] = 0.f; B00[g] = 0.f; B01[g] = 0.f; B11[g] = 0.f; C00[g] = 0.f; C01[g] = 0.f; C11[g] = 0.f;
+    }
     const float* tr = tile;
     const float* ti = tile + l.tile_len;
     const int j0 = i16, j1 = 16 + i16;
@@ -72,14 +78,15 @@ __global__ __launch_bounds__(NT, 4) void k_eq_bwd_cx(Lay l, const float* __restr
             const float rho1 = g0 * xa1 + g1 * xb1, sig1 = g1 * xa1 - g0 * xb1;
             const float ca0 = ones0 ? 1.f : xa0, cb0 = ones0 ? 0.f : xb0;
             const float ca1 = ones1 ? 1.f : xa1, cb1 = ones1 ? 0.f : xb1;
-            Rr00 = MFMA16(rho0, ca0, Rr00); Ri00 = MFMA16(sig0, ca0, Ri00);
-            Rr01 = MFMA16(rho0, ca1, Rr01); Ri01 = MFMA16(sig0, ca1, Ri01);
-            Rr11 = MFMA16(rho1, ca1, Rr11); Ri11 = MFMA16(sig1, ca1, Ri11);
-            Rr00 = MFMA16(sig0, cb0, Rr00); Ri00 = MFMA16(-rho0, cb0, Ri00);
-            Rr01 = MFMA16(sig0, cb1, Rr01); Ri01 = MFMA16(-rho0, cb1, Ri01);
-            Rr11 = MFMA16(sig1, cb1, Rr11); Ri11 = MFMA16(-rho1, cb1, Ri11);
+            const float rs0 = rho0 + sig0, rs1 = rho1 + sig1;
+            const float cs0 = ca0 + cb0, cs1 = ca1 + cb1, cd0 = ca0 - cb0, cd1 = ca1 - cb1;
+            A00 = MFMA16(rs0, ca0, A00); B00 = MFMA16(-rho0, cs0, B00); C00 = MFMA16(sig0, cd0, C00);
+            A01 = MFMA16(rs0, ca1, A01); B01 = MFMA16(-rho0, cs1, B01); C01 = MFMA16(sig0, cd1, C01);
+            A11 = MFMA16(rs1, ca1, A11); B11 = MFMA16(-rho1, cs1, B11); C11 = MFMA16(sig1, cd1, C11);
         }
     }
+    const f32x4 Rr00 = A00 - C00, Rr01 = A01 - C01, Rr11 = A11 - C11;
+    const f32x4 Ri00 = A00 + B00, Ri01 = A01 + B01, Ri11 = A11 + B11;
     // fixed-order reduction of the four waves through LDS, then one record per block: [2 planes][32][32], block (1,0) left zero
     __syncthreads();
     float* img = sm;  // [2][1024]
