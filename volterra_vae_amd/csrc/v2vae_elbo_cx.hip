@@ -400,7 +400,7 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
 #endif
 
     // ---- one record per (block, phase); Ps block of the record is left zero (filled from the lagged sums later)
-    float* img = s_T + (size_t)r * CX_REC;  // NW * 32 * TP >= 4224 floats >= S * CX_REC
+    float* img = s_T + (size_t)r * CX_IMG;  // NW * 32 * TP >= 4224 floats >= S * CX_IMG
     float vsum[8][4];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -434,8 +434,17 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
         }
         __syncthreads();
     }
+    // record: Re = R00 + R11, Im = R10 - R01 of the 32x32 tile R = [rho | sigma]^T [mu_a | mu_b], then the vectors
     float* rec = ws + l.o_part_cx + (size_t)blockIdx.x * S * CX_REC;
-    for (int e = tid; e < S * CX_REC; e += CX2_NT) rec[e] = s_T[e];
+    for (int e = tid; e < S * CX_REC; e += CX2_NT) {
+        const int rr = e / CX_REC, q = e - rr * CX_REC;
+        const float* im = s_T + (size_t)rr * CX_IMG;
+        float v;
+        if (q < 256) { const int a = q >> 4, b = q & 15; v = im[a * 32 + b] + im[(16 + a) * 32 + 16 + b]; }
+        else if (q < 512) { const int a = (q - 256) >> 4, b = q & 15; v = im[(16 + a) * 32 + b] - im[a * 32 + 16 + b]; }
+        else v = im[2048 + (q - 512)];
+        rec[e] = v;
+    }
     double v = Eacc;
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     __syncthreads();
@@ -491,11 +500,12 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
     float* stg = s_W + wv * CX3_WAVE_F;        // [7][MS]
     f32x4* G4 = reinterpret_cast<f32x4*>(stg + 7 * MS);   // [MS] per-symbol gradients (d/d mean_a, mean_b, var_a, var_b) of the strip
     f32x4* Bd = G4 + MS;                       // [ADB] anti-diagonal buffer
-    float* Tb = reinterpret_cast<float*>(Bd);  // [32 * TP] transposing buffer of rho / sigma, in the same memory
-    static_assert(32 * CX_TP <= 4 * CX3_ADB && S * CX_REC <= CX3_WAVE_F, "shared regions");
+    float* Tr = reinterpret_cast<float*>(Bd);  // [32 windows][17] rho rows and, after them, sigma rows: the transposing buffers of
+    float* Ts = Tr + 32 * 17;                  // the dE/dH accumulation, in the same memory as the anti-diagonal buffer
+    static_assert(2 * 32 * 17 <= 4 * 16 * 32 && S * CX_REC <= CX3_WAVE_F, "shared regions");
+    const int i16 = lane & 15, kq = lane >> 4;
     const float* __restrict__ mom = ws + l.o_mom;
     const int64_t own_hi = l.own_lo + l.own_cnt, sym_hi = l.sym_lo + l.sym_cnt, st = l.sym_cnt;
-    const int cj = i >> 4, yj = i & 15;
 
     // ---- constants of every phase into LDS
     for (int idx = tid; idx < S * 2 * NK * 64; idx += CX3_NT) {
@@ -532,9 +542,10 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
 #ifdef V2VAE_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
 #endif
-    f32x16 R;
-#pragma unroll
-    for (int g = 0; g < 16; ++g) R[g] = 0.f;
+    // dE/dH = sum over windows of (rho + i sigma)^T conj(X), a complex 16x16 accumulation, from three real products instead of
+    // four:  K1 = (rho + sigma)^T mu_a,  K2 = -rho^T (mu_a + mu_b),  K3 = sigma^T (mu_a - mu_b);  Re = K1 - K3, Im = K1 + K2
+    // (combined once at the end: the sums are linear).  16x16x4 MFMAs, four windows per k-step.
+    f32x4 K1 = {0.f, 0.f, 0.f, 0.f}, K2 = K1, K3 = K1;
     f2 ghr[4], ghi[4], gdr[4], gdi[4];  // vector gradients of the tap pairs (2 p, 2 p + 1)
 #pragma unroll
     for (int p = 0; p < 4; ++p) { ghr[p] = 0.f; ghi[p] = 0.f; gdr[p] = 0.f; gdi[p] = 0.f; }
@@ -629,9 +640,7 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
             fetch32(ts + tsl + 48);                  // the group the next slab (of this or of the next strip) will add
             __builtin_amdgcn_wave_barrier();
 
-            f32x16 U;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) U[g] = 0.f;
+            f32x16 U = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < NK; ++s) {
                 // k = 2 s + h over [stream][NK taps]
@@ -692,9 +701,7 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
 
             STAMP(2);
             // ---- H w: k-slot (s, h) carries the (stream, tap) of cx3_hw_slot
-            f32x16 HW;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) HW[g] = 0.f;
+            f32x16 HW = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (NK == 16) {
 #pragma unroll
                 for (int s = 0; s < 16; ++s)
@@ -752,16 +759,20 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
                 gdr[p] += (mo * 2.f * e0) * dvv[p];
                 gdi[p] += (mo * 2.f * e1) * dvv[p];
                 const f2 t0 = mo * (gr + 2.f * al[p]), t1 = mo * (gi + 2.f * be[p]);
-                Tb[i * TP + x] = t0.x;
-                Tb[i * TP + x + 1] = t0.y;
-                Tb[i * TP + 16 + x] = t1.x;
-                Tb[i * TP + 16 + x + 1] = t1.y;
+                Tr[i * 17 + x] = t0.x;
+                Tr[i * 17 + x + 1] = t0.y;
+                Ts[i * 17 + x] = t1.x;
+                Ts[i * 17 + x + 1] = t1.y;
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int w = 2 * s + h;
-                R = MFMA32(Tb[w * TP + i], s_mu[cj * MS + tsl + w + yj], R);
+            for (int s = 0; s < 8; ++s) {
+                const int w = 4 * s + kq;   // window of this lane's k-slot; tap i16
+                const float rho = Tr[w * 17 + i16], sig = Ts[w * 17 + i16];
+                const float ma = s_mu[tsl + w + i16], mb = s_mu[MS + tsl + w + i16];
+                K1 = MFMA16(rho + sig, ma, K1);
+                K2 = MFMA16(-rho, ma + mb, K2);
+                K3 = MFMA16(sig, ma - mb, K3);
             }
             __builtin_amdgcn_wave_barrier();
             STAMP(5);
@@ -800,13 +811,14 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
         }
         vsum[q][0] = v0; vsum[q][1] = v1; vsum[q][2] = v2; vsum[q][3] = v3;
     }
+    const f32x4 Re = K1 - K3, Im = K1 + K2;
     for (int w = 0; w < NWP; ++w) {
         if (wsub == w) {
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int e = ((g & 3) + 8 * (g >> 2) + 4 * h) * 32 + i;
-                if (w == 0) { img[e] = R[g]; img[1024 + e] = 0.f; }
-                else img[e] += R[g];
+            for (int g = 0; g < 4; ++g) {
+                const int e = (4 * kq + g) * 16 + i16;
+                if (w == 0) { img[e] = Re[g]; img[256 + e] = Im[g]; }
+                else { img[e] += Re[g]; img[256 + e] += Im[g]; }
             }
             if (i == 0) {
 #pragma unroll
@@ -814,8 +826,8 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
                     const int x = cx_kk(q, h);
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
-                        if (w == 0) img[2048 + v * 16 + x] = vsum[q][v];
-                        else img[2048 + v * 16 + x] += vsum[q][v];
+                        if (w == 0) img[512 + v * 16 + x] = vsum[q][v];
+                        else img[512 + v * 16 + x] += vsum[q][v];
                     }
                 }
             }
@@ -1098,7 +1110,7 @@ __global__ __launch_bounds__(NT) void k_chain_channel_cx(Lay l, const float* __r
             const int p = idx / L, tap = idx - p * L;
             int r, x;
             compact(tap, &r, &x);
-            g_h1[idx] = lam * ws[l.o_tot_cx + (size_t)r * CX_REC + 2048 + p * 16 + x];
+            g_h1[idx] = lam * ws[l.o_tot_cx + (size_t)r * CX_REC + 512 + p * 16 + x];
         } else {
             if (!g_h2) continue;
             const int e = idx - n1;
@@ -1110,13 +1122,12 @@ __global__ __launch_bounds__(NT) void k_chain_channel_cx(Lay l, const float* __r
             float v = 0.f;
             if (ri == rj) {
                 const float* tot = ws + l.o_tot_cx + (size_t)ri * CX_REC;
-                const float* Rm = tot;
                 const float* Hp = ws + l.o_cxH + (size_t)(ri * 2 + p) * 256;
                 const float ps = ws[l.o_psv + ((size_t)ri * l.LE + xi) * l.LE + xj];   // lagged sum of the tap pair (k_g2_cx)
                 auto G = [&](int a, int b) {
-                    float g = (p == 0) ? Rm[a * 32 + b] + Rm[(16 + a) * 32 + 16 + b] : Rm[(16 + a) * 32 + b] - Rm[a * 32 + 16 + b];
+                    float g = tot[p * 256 + a * 16 + b];
                     g += 4.f * Hp[a * 16 + b] * ps;
-                    if (a == b) g += tot[2048 + (2 + p) * 16 + a];
+                    if (a == b) g += tot[512 + (2 + p) * 16 + a];
                     return g;
                 };
                 v = G(xi, xj) + G(xj, xi);

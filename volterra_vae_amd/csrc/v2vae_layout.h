@@ -24,7 +24,9 @@ constexpr int SCRATCH_F = 4096; // floats of LDS scratch for cross-chunk reducti
 constexpr int MAX_BLOCKS = 512; // persistent workgroups per kernel (2 per CU)
 // matrix-core ELBO kernel for the complex model (v2vae_elbo_cx.hip)
 constexpr int CX_TP = 33;            // row pitch of the per-wave transposing buffer
-constexpr int CX_REC = 2112;         // floats per wave record: R 32x32, Ps 32x32, 4 vectors of 16
+constexpr int CX_REC = 576;          // floats per (workgroup, phase) record of the matrix-core ELBO kernels (<= 16 taps): the complex
+                                     // 16x16 accumulation sum (rho + i sigma)^T conj(X) as Re [16][16], Im [16][16], then 4 vectors of 16
+constexpr int CX_IMG = 2112;         // floats of the block-tile kernel's LDS image of its 32x32 accumulator tile (+ vectors)
 constexpr int SUM_CHUNKS = 32;       // first-stage groups of the two-stage partial-record sums
 constexpr int CX_BLOCKS = 256;       // one workgroup per CU (the LDS image takes most of a CU)
 constexpr int CXB_TWB = 256;         // windows per phase per block tile of the blocked kernel
