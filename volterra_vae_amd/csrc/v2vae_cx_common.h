@@ -63,14 +63,15 @@ __device__ __forceinline__ float cx_s_at(const Lay& l, const float* __restrict__
 }
 
 // sum over the owned, valid windows t of phase r of s[t + a] s[t + b]
-__device__ __forceinline__ float psum_value(const Lay& l, const float* __restrict__ ws, int r, int a, int b) {
+// `tot` = the lagged products over all owned symbols (doubles, one per lag)
+__device__ __forceinline__ float psum_value(const Lay& l, const float* __restrict__ ws, const double* tot, int r, int a, int b) {
     const float* __restrict__ mom = ws + l.o_mom;
     const int kk = a < b ? a : b, d = a < b ? b - a : a - b;
     const int64_t lo = l.own_lo, hi = l.own_lo + l.own_cnt;
     const int64_t Tr = (l.W - 1 - r >= 0) ? (l.W - 1 - r) / l.S + 1 : 0;
     const int64_t br = hi < Tr ? hi : Tr;
     if (br <= lo) return 0.f;
-    double v = reinterpret_cast<const double*>(ws + l.o_psum_tot)[d];
+    double v = tot[d];
     auto c = [&](int64_t m) { return (double)(cx_s_at(l, mom, m) * cx_s_at(l, mom, m + d)); };
     for (int64_t m = lo; m < lo + kk; ++m) v -= c(m);
     const int64_t last = br - 1 + kk;

@@ -931,12 +931,32 @@ __global__ __launch_bounds__(NT, 5) void k_g2_cx(Lay l, float* __restrict__ ws) 
     const int bid = (int)blockIdx.x - G2_NE;
 
     if (bid < 0) {
+        // totals of the lagged products over the workgroups of k_psum_cx, fixed order (thread (lag d, chunk c) sums workgroups
+        // c, c + nchunk, ...; then the chunks in order); every one of these few workgroups forms them for itself
+        __shared__ double s_pp[NT];
+        __shared__ double s_tot[NLAG];
+        {
+            const int nchunk = NT / NLAG;
+            const int d = threadIdx.x % NLAG, c = threadIdx.x / NLAG;
+            const double* part = reinterpret_cast<const double*>(ws + l.o_psum_part);
+            double s = 0.0;
+            if (c < nchunk)
+                for (int b = c; b < l.nblk_psum; b += nchunk) s += part[(size_t)b * NLAG + d];
+            s_pp[threadIdx.x] = s;
+            __syncthreads();
+            if (threadIdx.x < NLAG) {
+                double t = 0.0;
+                for (int k = 0; k < nchunk; ++k) t += s_pp[k * NLAG + threadIdx.x];
+                s_tot[threadIdx.x] = t;
+            }
+            __syncthreads();
+        }
         double v = 0.0;
         for (int it = (int)blockIdx.x + G2_NE * (int)threadIdx.x; it < S * LE * LE; it += G2_NE * NT) {
             const int r = it / (LE * LE), rem = it - r * LE * LE;
             const int x = rem / LE, j = rem - x * LE;
             const float hh = ws[l.o_HHc + ((size_t)(r * 2 + 0) * LTp + x) * LTp + j] + ws[l.o_HHc + ((size_t)(r * 2 + 1) * LTp + x) * LTp + j];
-            const float ps = psum_value(l, ws, r, x, j);
+            const float ps = psum_value(l, ws, s_tot, r, x, j);
             ws[l.o_psv + it] = ps;   // kept for the chain rule of dE/dH
             v += 2.0 * (double)hh * (double)ps;
         }
@@ -1074,24 +1094,6 @@ __global__ __launch_bounds__(NT, 5) void k_g2_cx(Lay l, float* __restrict__ ws) 
     }
 }
 
-// totals over the blocks, fixed order: thread (lag d, chunk c) sums blocks c, c + nchunk, ...; then the chunks in order
-__global__ __launch_bounds__(NT) void k_psum_finish_cx(Lay l, float* __restrict__ ws, int nlag) {
-    __shared__ double red[NT];
-    const int nchunk = NT / nlag;
-    const int d = threadIdx.x % nlag, c = threadIdx.x / nlag;
-    const double* part = reinterpret_cast<const double*>(ws + l.o_psum_part);
-    double s = 0.0;
-    if (c < nchunk)
-        for (int b = c; b < l.nblk_psum; b += nchunk) s += part[(size_t)b * nlag + d];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x < nlag) {
-        double t = 0.0;
-        for (int k = 0; k < nchunk; ++k) t += red[k * nlag + threadIdx.x];
-        reinterpret_cast<double*>(ws + l.o_psum_tot)[threadIdx.x] = t;
-    }
-}
-
 // raw gradients of the complex channel kernels from the per-phase totals
 __global__ __launch_bounds__(NT) void k_chain_channel_cx(Lay l, const float* __restrict__ ws, const double* __restrict__ scal,
                                                          const float* __restrict__ grad_scale, float* __restrict__ g_h1,
@@ -1163,11 +1165,9 @@ void launch_psum_cx(const Lay& l, float* ws, hipStream_t st) {
     const int ng = (int)(nt < 4096 ? (nt > 0 ? nt : 1) : 4096);
     if (l.use_cxb) {
         hipLaunchKernelGGL(k_psum_cx<CX_MAXLAG>, dim3(l.nblk_psum), dim3(NT), 0, st, l, ws);
-        hipLaunchKernelGGL(k_psum_finish_cx, dim3(1), dim3(NT), 0, st, l, ws, CX_MAXLAG);
         hipLaunchKernelGGL(k_g2_cx<CX_MAXLAG>, dim3(ng + G2_NE), dim3(NT), 0, st, l, ws);
     } else {
         hipLaunchKernelGGL(k_psum_cx<16>, dim3(l.nblk_psum), dim3(NT), 0, st, l, ws);
-        hipLaunchKernelGGL(k_psum_finish_cx, dim3(1), dim3(NT), 0, st, l, ws, 16);
         hipLaunchKernelGGL(k_g2_cx<16>, dim3(ng + G2_NE), dim3(NT), 0, st, l, ws);   // + G2_NE: the lagged-product term of E
     }
 }

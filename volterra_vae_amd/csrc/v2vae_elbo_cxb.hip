@@ -210,7 +210,6 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
         const float* s_S = s_mu + 2 * MS;
         const float* s_yw = s_S + MS;
         const bool more = tile + (int)gridDim.x < l.ntile_cxb;
-        if (more) stage_load(tile + gridDim.x);
 
         BSTAMP(0);
         for (int sub = wsub; sub < NU; sub += NWP) {
@@ -396,7 +395,9 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
         }
         __syncthreads();
         BSTAMP(6);
-        if (more) stage_store(s_stage);
+        // the next tile is fetched here, not during the slabs: the 36 registers it would occupy across them are worth more than the
+        // load latency exposed once per tile (four slabs per wave)
+        if (more) { stage_load(tile + gridDim.x); stage_store(s_stage); }
         // ---- gather: symbol slot ms = kmax + ml collects the partials of every slab whose 32 + Le - 1 slots cover it
         for (int idx = tid; idx < 2 * TS; idx += CXB_NT) {
             const int c = idx / TS, ml = idx - c * TS;

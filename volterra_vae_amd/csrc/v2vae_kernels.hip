@@ -902,7 +902,10 @@ __global__ __launch_bounds__(NT) void k_eq_bwd(Lay l, const float* __restrict__ 
 // ------------------------------------------------------------------------------------------
 // fused ELBO forward + backward over sliding windows (polyphase form)
 // ------------------------------------------------------------------------------------------
-template <int MAXI>
+// DIAG: the second-order kernel is diagonal (memory-polynomial and Hammerstein channel models,
+// lib/real_equalization.py:1304-1354, :1117-1167): H mu, (H.H) v and H w are element-wise products and of dE/dH only the
+// diagonal is formed, so the work per window is O(taps) instead of O(taps^2).
+template <int MAXI, bool DIAG>
 __device__ __forceinline__ void d_elbo(const GridCtx gc, Lay l, const float* __restrict__ y, float* __restrict__ ws) {
     extern __shared__ float sm[];
     const int TW = l.TWIN, TSYM = l.TSYM, LTp = l.LTp, NS = l.ns, NG = l.NG;
@@ -949,6 +952,7 @@ __device__ __forceinline__ void d_elbo(const GridCtx gc, Lay l, const float* __r
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[s][e] = 0.f;
         double v1 = 0.0, v2 = 0.0, v3 = 0.0;  // gh1, gd, gdq of vector item (o,k) = tid
+        double v4 = 0.0, v5 = 0.0;            // DIAG: diagonal entries (k, k) of the two matrix gradients
 
         for (int tile = gc.bid; tile < l.ntile_elbo; tile += gc.nb) {
             const int64_t s0 = l.own_lo + (int64_t)tile * l.TS;
@@ -985,6 +989,15 @@ __device__ __forceinline__ void d_elbo(const GridCtx gc, Lay l, const float* __r
                 for (int u = g; u < nb; u += NG) {
                     const int k0 = u * 4;
                     float uu[4] = {0.f, 0.f, 0.f, 0.f}, tt[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (DIAG) {   // NS == 1
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int k = k0 + i;
+                            const float hd = Ho[(size_t)k * LTp + k];
+                            uu[i] = hd * s_mom[ts + k];
+                            tt[i] = hd * hd * s_mom[TSYM + ts + k];
+                        }
+                    } else
                     for (int c = 0; c < NS; ++c) {
                         const float* mrow = s_mom + (c * 4 + 0) * TSYM + ts;
                         const float* vrow = s_mom + (c * 4 + 1) * TSYM + ts;
@@ -1052,6 +1065,10 @@ __device__ __forceinline__ void d_elbo(const GridCtx gc, Lay l, const float* __r
                 for (int o = 0; o < NS; ++o) {
                     const float* __restrict__ Ho = Hc + (size_t)o * LTp * LTp;
                     float hw[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (DIAG) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) hw[i] = Ho[(size_t)(k0 + i) * LTp + k0 + i] * s_w[(o * LTp + k0 + i) * TW + ts];
+                    } else
                     for (int c = 0; c < NS; ++c)
                         for (int kk = 0; kk < l.LE; ++kk) {
                             const int j = c * l.LEp + kk;
@@ -1099,8 +1116,8 @@ __device__ __forceinline__ void d_elbo(const GridCtx gc, Lay l, const float* __r
                     else { gp[0] += a0; gp[l.sym_cnt] += a1; gp[2 * l.sym_cnt] += a2; gp[3 * l.sym_cnt] += a3; }
                 }
             }
-            // ---- E2: parameter-gradient outer products over this tile's owned windows
-            if (active) {
+            // ---- E2: parameter-gradient outer products over this tile's owned windows (DIAG: only their diagonals, in E3)
+            if (!DIAG && active) {
 #pragma unroll
                 for (int s = 0; s < MAXI; ++s) {
                     const int it = item0 + s * NT;
@@ -1143,7 +1160,7 @@ __device__ __forceinline__ void d_elbo(const GridCtx gc, Lay l, const float* __r
                 const int c = k / l.LEp, kk = k - c * l.LEp;
                 const float dk = dc[o * LTp + k];
                 const float* mb = s_mom + c * 4 * TSYM + kk;
-                float f1 = 0.f, f2 = 0.f, f3 = 0.f;
+                float f1 = 0.f, f2 = 0.f, f3 = 0.f, f4 = 0.f, f5 = 0.f;
                 for (int t = 0; t < TW; ++t) {
                     const float wgt = s_ow[t];
                     const float mk = mb[t], vk = mb[TSYM + t], kp = mb[2 * TSYM + t], gm = mb[3 * TSYM + t];
@@ -1152,8 +1169,13 @@ __device__ __forceinline__ void d_elbo(const GridCtx gc, Lay l, const float* __r
                     f1 += wgt * (2.f * e * mk + w);
                     f2 += wgt * (2.f * A * vk + 2.f * kp * z + 2.f * gm * dk);
                     f3 += wgt * (-2.f * yv * vk);
+                    if (DIAG) {   // diagonal of the two outer-product accumulations of E2
+                        f4 += wgt * fmaf(e, mk, w) * mk;
+                        f5 += wgt * vk * vk;
+                    }
                 }
                 v1 += (double)f1; v2 += (double)f2; v3 += (double)f3;
+                if (DIAG) { v4 += (double)f4; v5 += (double)f5; }
             }
         }
         // ---- flush this phase's partial sums
@@ -1162,7 +1184,13 @@ __device__ __forceinline__ void d_elbo(const GridCtx gc, Lay l, const float* __r
         float* partP = part + NS * LTp * LTp;
         float* partV = partP + LTp * LTp;
         __syncthreads();
-        if (MAXI == 1 && l.nitems_elbo <= NT) {
+        if (DIAG) {
+            if (tid < NS * LTp) {
+                const int o = tid / LTp, k = tid - o * LTp;
+                partG[((size_t)o * LTp + k) * LTp + k] = 2.f * (float)v4;
+                if (o == 0) partP[(size_t)k * LTp + k] = (float)v5;
+            }
+        } else if (MAXI == 1 && l.nitems_elbo <= NT) {
             for (int base = 0; base < nchunk; ++base) {
                 __syncthreads();
                 if (active && chunk == base)
@@ -1211,9 +1239,9 @@ __device__ __forceinline__ void d_elbo(const GridCtx gc, Lay l, const float* __r
     if (tid == 0) reinterpret_cast<double*>(ws + l.o_Epart)[gc.bid] = s;
 }
 
-template <int MAXI>
+template <int MAXI, bool DIAG>
 __global__ __launch_bounds__(NT) void k_elbo(Lay l, const float* __restrict__ y, float* __restrict__ ws) {
-    d_elbo<MAXI>(GridCtx{(int)blockIdx.x, (int)gridDim.x}, l, y, ws);
+    d_elbo<MAXI, DIAG>(GridCtx{(int)blockIdx.x, (int)gridDim.x}, l, y, ws);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1578,7 +1606,8 @@ __global__ __launch_bounds__(NT) void k_fit_persistent(Lay l, v2vae_fit_args a, 
             __syncthreads();
         }
         for (int b = 0; b < l.nblk_elbo; ++b) {
-            d_elbo<1>(GridCtx{b, l.nblk_elbo}, l, yb, ws);
+            if (l.chan) d_elbo<1, true>(GridCtx{b, l.nblk_elbo}, l, yb, ws);
+            else d_elbo<1, false>(GridCtx{b, l.nblk_elbo}, l, yb, ws);
             __syncthreads();
         }
         d_reduce_scalars(one, l, ws, scal);
@@ -1758,15 +1787,16 @@ int v2vae_elbo_fused(const v2vae_problem* p, const float* y, void* ws, void* str
         rc = launch_elbo_cxb(l, y, (float*)ws, st);
         return rc ? rc : launch_status();
     }
-#define V2VAE_LAUNCH_ELBO(M)                                                                              \
-    do {                                                                                                  \
-        rc = allow_lds(k_elbo<M>, l.lds_elbo);                                                            \
-        if (rc) return rc;                                                                                \
-        hipLaunchKernelGGL(k_elbo<M>, dim3(l.nblk_elbo), dim3(NT), l.lds_elbo, st, l, y, (float*)ws);     \
+#define V2VAE_LAUNCH_ELBO(M, D)                                                                               \
+    do {                                                                                                      \
+        rc = allow_lds((k_elbo<M, D>), l.lds_elbo);                                                           \
+        if (rc) return rc;                                                                                    \
+        hipLaunchKernelGGL((k_elbo<M, D>), dim3(l.nblk_elbo), dim3(NT), l.lds_elbo, st, l, y, (float*)ws);   \
     } while (0)
-    if (l.maxi_elbo == 1) V2VAE_LAUNCH_ELBO(1);
-    else if (l.maxi_elbo == 2) V2VAE_LAUNCH_ELBO(2);
-    else V2VAE_LAUNCH_ELBO(4);
+    if (l.chan) V2VAE_LAUNCH_ELBO(1, true);   // diagonal kernel (polynomial channel models): O(taps) per window
+    else if (l.maxi_elbo == 1) V2VAE_LAUNCH_ELBO(1, false);
+    else if (l.maxi_elbo == 2) V2VAE_LAUNCH_ELBO(2, false);
+    else V2VAE_LAUNCH_ELBO(4, false);
 #undef V2VAE_LAUNCH_ELBO
     return launch_status();
 }
