@@ -299,7 +299,7 @@ def main():
             with open(os.path.join(ROOT, "profiles", "latest_traffic.json")) as fh:
                 tr = json.load(fh)
             if dom == "elbo_fused" and world == 1 and args.log2_symbols == 22 and (L, l1, order) == (25, 25, 16):
-                traffic = next(v for k, v in tr.items() if "k_elbo_cx2" in k)
+                traffic = next(v for k, v in tr.items() if "k_elbo_cx" in k)
         except Exception:
             traffic = None
         out = {
