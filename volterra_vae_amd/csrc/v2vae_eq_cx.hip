@@ -1,5 +1,5 @@
-// Complex second-order Volterra equaliser on the f32 matrix cores: backward for kernels of up to 31 lags (the forward of every
-// length and the backward of longer kernels live in v2vae_eq_cxb.hip).
+// Complex second-order Volterra equaliser on the f32 matrix cores: backward for kernels of up to 79 lags (the forward of every
+// length and the backward of still longer kernels live in v2vae_eq_cxb.hip).
 //
 // xhat_b = sum_j k1[j] y[bS + j - p1] + Y_b^T K Y_b,  K = k2 + k2^T complex symmetric, Y_b[x] = y[bS + p2 - x],
 // Y = Ya + j Yb.
@@ -9,7 +9,7 @@
 // upper-triangular 16x16 blocks per wave, as three real products each (see the kernel), 16x16x4 MFMAs, four symbols per k-step; a
 // ones column at index l2 of the Ya operand (zero in the Yb operand) yields the first-order gradient in the same products.
 //
-// Applies when mode = complex, l2 odd <= 31, l1 odd <= l2 and pad1 = l1 / 2.
+// Applies when mode = complex, l2 odd <= 79, l1 odd <= l2 and pad1 = l1 / 2 (lag rows in 1 .. 5 blocks of 16).
 #include <hip/hip_runtime.h>
 
 #include "v2vae_layout.h"
@@ -33,29 +33,37 @@ __device__ __forceinline__ void eqcx_load_tile(const Lay& l, const float* __rest
     }
 }
 
-__global__ __launch_bounds__(NT, 4) void k_eq_bwd_cx(Lay l, const float* __restrict__ y, const float* __restrict__ gx,
-                                                  float* __restrict__ ws) {
+// NB16 = blocks of 16 lag rows (lags 0 .. l2, the ones column at index l2 included): 2 for up to 31 lags, ... 5 for up to 79.
+template <int NB16>
+__global__ __launch_bounds__(NT, NB16 <= 3 ? 4 : 2) void k_eq_bwd_cx(Lay l, const float* __restrict__ y, const float* __restrict__ gx,
+                                                                  float* __restrict__ ws) {
+    constexpr int NBLK = NB16 * (NB16 + 1) / 2, LD = 16 * NB16;
     extern __shared__ float sm[];
     float* tile = sm;
     float* gt = tile + l.ns * l.tile_len;  // [2][EQ_TB]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int i16 = lane & 15, kq = lane >> 4;
-    // Both gradient planes are symmetric in the lag pair, so of the 2 x 2 blocks of 16 lags only (0,0), (0,1), (1,1) are
-    // accumulated (16x16x4 MFMAs, four symbols per k-step); the chain rule reads block (1,0) from (0,1).
+    // Both gradient planes are symmetric in the lag pair, so only the upper-triangular 16x16 blocks (ib <= jb) are
+    // accumulated (16x16x4 MFMAs, four symbols per k-step); the chain rule reads a lower block from its transpose.
     // The complex accumulation dK_r + i dK_i = sum (rho + i sigma)^T (Ya - i Yb) is formed from THREE real products per block
     // instead of four:  K1 = (rho + sigma)^T Ya,  K2 = -rho^T (Ya + Yb),  K3 = sigma^T (Ya - Yb);  dK_r = K1 - K3, dK_i = K1 + K2.
-    // The sums are linear, so K1, K2, K3 are accumulated over all symbols and combined once at the end: 9 MFMAs per k-step
-    // instead of 12.  The ones column (first-order gradient) sits in Ya only; its Yb entry is zero in all three operands.
-    f32x4 A00, A01, A11, B00, B01, B11, C00, C01, C11;
+    // The sums are linear, so K1, K2, K3 are accumulated over all symbols and combined once at the end.  The ones column
+    // (first-order gradient) sits in Ya only; its Yb entry is zero in all three operands.
+    f32x4 A[NBLK], B[NBLK], C[NBLK];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        A00[g] = 0.f; A01[g] = 0.f; A11[g] = 0.f; B00[g] = 0.f; B01[g] = 0.f; B11[g] = 0.f; C00[g] = 0.f; C01[g] = 0.f; C11[g] = 0.f;
-    }
+    for (int q = 0; q < NBLK; ++q)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { A[q][g] = 0.f; B[q][g] = 0.f; C[q][g] = 0.f; }
     const float* tr = tile;
     const float* ti = tile + l.tile_len;
-    const int j0 = i16, j1 = 16 + i16;
-    const bool ones0 = (j0 == l.l2), ones1 = (j1 == l.l2);
-    const int jc0 = j0 <= l.l2 ? j0 : l.l2, jc1 = j1 <= l.l2 ? j1 : l.l2;  // rows / columns beyond l2 are never read back
+    int jc[NB16];
+    bool ones[NB16];
+#pragma unroll
+    for (int ib = 0; ib < NB16; ++ib) {
+        const int j = 16 * ib + i16;
+        ones[ib] = (j == l.l2);
+        jc[ib] = j <= l.l2 ? j : l.l2;   // rows / columns beyond l2 are never read back
+    }
     for (int t = blockIdx.x; t < l.ntile_eq; t += gridDim.x) {
         const int64_t b0 = l.own_lo + (int64_t)t * EQ_TB;
         const int64_t rem = l.own_lo + l.own_cnt - b0;
@@ -68,60 +76,75 @@ __global__ __launch_bounds__(NT, 4) void k_eq_bwd_cx(Lay l, const float* __restr
         }
         __syncthreads();
         const int wbase = wv * 64;
-#pragma unroll 4
+#pragma unroll(NB16 <= 2 ? 2 : 1)
         for (int s = 0; s < 16; ++s) {
             const int bloc = wbase + 4 * s + kq;
             const int base = bloc * l.S + l.hl + l.p2;
-            const float xa0 = tr[base - jc0], xb0 = ti[base - jc0], xa1 = tr[base - jc1], xb1 = ti[base - jc1];
             const float g0 = gt[bloc], g1 = gt[EQ_TB + bloc];
-            const float rho0 = g0 * xa0 + g1 * xb0, sig0 = g1 * xa0 - g0 * xb0;
-            const float rho1 = g0 * xa1 + g1 * xb1, sig1 = g1 * xa1 - g0 * xb1;
-            const float ca0 = ones0 ? 1.f : xa0, cb0 = ones0 ? 0.f : xb0;
-            const float ca1 = ones1 ? 1.f : xa1, cb1 = ones1 ? 0.f : xb1;
-            const float rs0 = rho0 + sig0, rs1 = rho1 + sig1;
-            const float cs0 = ca0 + cb0, cs1 = ca1 + cb1, cd0 = ca0 - cb0, cd1 = ca1 - cb1;
-            A00 = MFMA16(rs0, ca0, A00); B00 = MFMA16(-rho0, cs0, B00); C00 = MFMA16(sig0, cd0, C00);
-            A01 = MFMA16(rs0, ca1, A01); B01 = MFMA16(-rho0, cs1, B01); C01 = MFMA16(sig0, cd1, C01);
-            A11 = MFMA16(rs1, ca1, A11); B11 = MFMA16(-rho1, cs1, B11); C11 = MFMA16(sig1, cd1, C11);
+            float rs[NB16], nrho[NB16], sig[NB16], ca[NB16], cs[NB16], cd[NB16];
+#pragma unroll
+            for (int ib = 0; ib < NB16; ++ib) {
+                const float xa = tr[base - jc[ib]], xb = ti[base - jc[ib]];
+                const float rho = g0 * xa + g1 * xb;
+                sig[ib] = g1 * xa - g0 * xb;
+                nrho[ib] = -rho;
+                rs[ib] = rho + sig[ib];
+                ca[ib] = ones[ib] ? 1.f : xa;
+                const float cb = ones[ib] ? 0.f : xb;
+                cs[ib] = ca[ib] + cb;
+                cd[ib] = ca[ib] - cb;
+            }
+#pragma unroll
+            for (int ib = 0; ib < NB16; ++ib)
+#pragma unroll
+                for (int jb = ib; jb < NB16; ++jb) {
+                    const int q = ib * NB16 - ib * (ib - 1) / 2 + (jb - ib);
+                    A[q] = MFMA16(rs[ib], ca[jb], A[q]);
+                    B[q] = MFMA16(nrho[ib], cs[jb], B[q]);
+                    C[q] = MFMA16(sig[ib], cd[jb], C[q]);
+                }
         }
     }
-    const f32x4 Rr00 = A00 - C00, Rr01 = A01 - C01, Rr11 = A11 - C11;
-    const f32x4 Ri00 = A00 + B00, Ri01 = A01 + B01, Ri11 = A11 + B11;
-    // fixed-order reduction of the four waves through LDS, then one record per block: [2 planes][32][32], block (1,0) left zero
+    // fixed-order reduction of the four waves through LDS, then one record per block: [2 planes][LD][LD], lower blocks left zero
     __syncthreads();
-    float* img = sm;  // [2][1024]
-    for (int e = tid; e < 2048; e += NT) img[e] = 0.f;
+    float* img = sm;  // [2][LD * LD]
+    for (int e = tid; e < 2 * LD * LD; e += NT) img[e] = 0.f;
     __syncthreads();
     for (int w = 0; w < 4; ++w) {
         if (wv == w) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int a = 4 * kq + g, b = i16;
-                img[a * 32 + b] += Rr00[g];             img[1024 + a * 32 + b] += Ri00[g];
-                img[a * 32 + 16 + b] += Rr01[g];        img[1024 + a * 32 + 16 + b] += Ri01[g];
-                img[(16 + a) * 32 + 16 + b] += Rr11[g]; img[1024 + (16 + a) * 32 + 16 + b] += Ri11[g];
-            }
+            for (int ib = 0; ib < NB16; ++ib)
+#pragma unroll
+                for (int jb = ib; jb < NB16; ++jb) {
+                    const int q = ib * NB16 - ib * (ib - 1) / 2 + (jb - ib);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int e = (16 * ib + 4 * kq + g) * LD + 16 * jb + i16;
+                        img[e] += A[q][g] - C[q][g];
+                        img[LD * LD + e] += A[q][g] + B[q][g];
+                    }
+                }
         }
         __syncthreads();
     }
-    float* rec = ws + l.o_part_eqcx + (size_t)blockIdx.x * 2048;
-    for (int e = tid; e < 2048; e += NT) rec[e] = img[e];
+    float* rec = ws + l.o_part_eqcx + (size_t)blockIdx.x * (2 * LD * LD);
+    for (int e = tid; e < 2 * LD * LD; e += NT) rec[e] = img[e];
 }
 
 __global__ __launch_bounds__(NT) void k_chain_equaliser_cx(Lay l, const float* __restrict__ ws, float* __restrict__ g_k1,
                                                            float* __restrict__ g_k2) {
     const float* T = ws + l.o_tot_eqcx;
-    const int l1 = l.l1, l2 = l.l2;
+    const int l1 = l.l1, l2 = l.l2, LD = 16 * l.eqb16, PL = LD * LD;
     const int n1 = 2 * l1, n2 = 2 * l2 * l2;
-    auto GK = [&](int p, int a, int b) {  // dE/dK (effective symmetric kernel), plane p
-        return (a >= 16 && b < 16) ? T[p * 1024 + b * 32 + a] : T[p * 1024 + a * 32 + b];   // block (1,0) = (0,1) transposed
+    auto GK = [&](int p, int a, int b) {  // dE/dK (effective symmetric kernel), plane p: a lower block is its partner transposed
+        return (a >> 4) > (b >> 4) ? T[p * PL + b * LD + a] : T[p * PL + a * LD + b];
     };
     for (int idx = blockIdx.x * NT + threadIdx.x; idx < n1 + n2; idx += gridDim.x * NT) {
         if (idx < n1) {
             if (!g_k1) continue;
             const int p = idx / l1, jj = idx - p * l1;
-            const int x = l.pad1 + l.p2 - jj;  // lag row that first-order tap jj multiplies
-            g_k1[idx] = T[p * 1024 + x * 32 + l2];
+            const int x = l.pad1 + l.p2 - jj;  // lag row that first-order tap jj multiplies (x < l2)
+            g_k1[idx] = T[p * PL + x * LD + l2];
         } else {
             if (!g_k2) continue;
             const int e = idx - n1;
@@ -133,7 +156,23 @@ __global__ __launch_bounds__(NT) void k_chain_equaliser_cx(Lay l, const float* _
 }
 
 int launch_eq_bwd_cx(const Lay& l, const float* y, const float* gx, float* ws, hipStream_t st) {
-    hipLaunchKernelGGL(k_eq_bwd_cx, dim3(l.nblk_eq), dim3(NT), l.lds_eq, st, l, y, gx, ws);
+    const int lds = l.lds_eqb16;
+#define V2VAE_LAUNCH_EQB16(NB)                                                                                                   \
+    do {                                                                                                                         \
+        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k_eq_bwd_cx<NB>),                                \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)               \
+            return V2VAE_ELAUNCH;                                                                                                \
+        hipLaunchKernelGGL(k_eq_bwd_cx<NB>, dim3(l.nblk_eq), dim3(NT), lds, st, l, y, gx, ws);                                    \
+    } while (0)
+    switch (l.eqb16) {
+        case 1: V2VAE_LAUNCH_EQB16(1); break;
+        case 2: V2VAE_LAUNCH_EQB16(2); break;
+        case 3: V2VAE_LAUNCH_EQB16(3); break;
+        case 4: V2VAE_LAUNCH_EQB16(4); break;
+        case 5: V2VAE_LAUNCH_EQB16(5); break;
+        default: return V2VAE_ESIZE;
+    }
+#undef V2VAE_LAUNCH_EQB16
     return V2VAE_OK;
 }
 

@@ -320,7 +320,7 @@ int launch_prep_eqcxb(const Lay& l, const float* k1, const float* k2, float* ws,
     return V2VAE_OK;
 }
 
-// Forward equaliser in symmetric form on the vector pipe, for kernels of up to 31 lags:
+// Forward equaliser in symmetric form on the vector pipe, for kernels of up to 65 lags (instances 9, 17, 25, 31, 47, 65):
 //   xhat = sum_a y_a (k1w_a + sum_{b >= a} K'_ab y_b),  K'_ab = K_ab (a = b), 2 K_ab (a < b),  y_x = y[b S + p2 - x],
 // T (T + 1) / 2 + T complex multiply-adds per symbol instead of the T^2 of the matrix product (the f32 matrix rate equals the
 // packed vector rate on this part, so half the multiply-adds and no padding of the lag count to 32 is what counts).  One
@@ -329,7 +329,7 @@ int launch_prep_eqcxb(const Lay& l, const float* k1, const float* k2, float* ws,
 typedef float eq_f2 __attribute__((ext_vector_type(2)));
 
 template <int T>
-__global__ __launch_bounds__(NT, 4) void k_eq_fwd_sym(Lay l, const float* __restrict__ y, const float* __restrict__ ws,
+__global__ __launch_bounds__(NT, T <= 31 ? 4 : 2) void k_eq_fwd_sym(Lay l, const float* __restrict__ y, const float* __restrict__ ws,
                                                       float* __restrict__ xhat) {
     extern __shared__ float sm[];
     float* tile = sm;
@@ -396,12 +396,15 @@ static int eqcxb_allow_lds(K kernel, int bytes) {
 int launch_eq_fwd_cxb(const Lay& l, const float* y, const float* ws, float* xhat, hipStream_t st) {
     int nblk = (int)((l.sym_cnt + EQ_TB - 1) / EQ_TB);
     if (l.eqsym_t && !(l.flags & V2VAE_FLAG_EQ_MFMA_FWD)) {
-        const int nb = nblk < 4 * CX_BLOCKS ? nblk : 4 * CX_BLOCKS;   // four resident workgroups per CU (launch bounds)
+        const int per_cu = l.eqsym_t <= 31 ? 4 : 2;                   // resident workgroups per CU (launch bounds)
+        const int nb = nblk < per_cu * CX_BLOCKS ? nblk : per_cu * CX_BLOCKS;
         const int lds = l.ns * l.tile_len * 4;
         if (l.eqsym_t == 9) hipLaunchKernelGGL(k_eq_fwd_sym<9>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat);
         else if (l.eqsym_t == 17) hipLaunchKernelGGL(k_eq_fwd_sym<17>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat);
         else if (l.eqsym_t == 25) hipLaunchKernelGGL(k_eq_fwd_sym<25>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat);
-        else hipLaunchKernelGGL(k_eq_fwd_sym<31>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat);
+        else if (l.eqsym_t == 31) hipLaunchKernelGGL(k_eq_fwd_sym<31>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat);
+        else if (l.eqsym_t == 47) hipLaunchKernelGGL(k_eq_fwd_sym<47>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat);
+        else hipLaunchKernelGGL(k_eq_fwd_sym<65>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat);
         return V2VAE_OK;
     }
     // persistent workgroups: as many per CU as their LDS image (sample tile + kernel table) allows, at most four

@@ -190,8 +190,14 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     if (l.use_eqcxb && l.lds_eqcxb_fwd > LDS_BUDGET) l.use_eqcxb = 0;
     // persistent backward kernels: exactly the workgroups that are resident at once (register use: 4 per CU for the
     // single-block kernel, 2 with two lag blocks, 1 with three), so that no partly filled second round trails the first
-    if (l.use_eqcx) l.nblk_eq = l.ntile_eq < 1024 ? l.ntile_eq : 1024;
-    if (l.use_eqcxb && l.eqcxb_nbl >= 3) l.nblk_eq = l.ntile_eq < 256 ? l.ntile_eq : 256;
+    l.eqb16 = (l.use_eqcx || (l.use_eqcxb && l.l2 <= 79)) ? (l.l2 + 1 + 15) / 16 : 0;
+    l.eqb16_rec = 2 * (16 * l.eqb16) * (16 * l.eqb16);
+    {
+        const int64_t a = l.lds_eq / 4, b = l.eqb16_rec;
+        l.lds_eqb16 = (int)((a > b ? a : b) * 4);
+    }
+    if (l.eqb16) l.nblk_eq = l.eqb16 <= 3 ? (l.ntile_eq < 1024 ? l.ntile_eq : 1024) : (l.ntile_eq < 512 ? l.ntile_eq : 512);
+    else if (l.use_eqcxb && l.eqcxb_nbl >= 3) l.nblk_eq = l.ntile_eq < 256 ? l.ntile_eq : 256;
     if (!generic_eq_ok && !l.use_eqcxb) return V2VAE_ESIZE;
     l.rec_elbo = l.S * rec_elbo_phase(l);
     l.rec_eq = l.ns * l.LT2p * l.LT2p + l.nk1;
@@ -235,13 +241,15 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     l.o_cxbc = take(l.use_cxb ? (int64_t)l.S * 4 * l.cxb_leb : 0);
     l.o_part_cxb = take(l.use_cxb ? (int64_t)l.nblk_cxb * l.S * l.cxb_rec : 0);
     l.o_tot_cxb = take(l.use_cxb ? (int64_t)l.S * l.cxb_rec : 0);
-    l.o_part_eqcx = take(l.use_eqcx ? (int64_t)l.nblk_eq * 2048 : 0);
-    l.o_tot_eqcx = take(l.use_eqcx ? 2048 : 0);
+    l.o_part_eqcx = take(l.eqb16 ? (int64_t)l.nblk_eq * l.eqb16_rec : 0);
+    l.o_tot_eqcx = take(l.eqb16 ? l.eqb16_rec : 0);
     l.o_eqcxbA = take(l.eqcxb_fwd ? (int64_t)l.eqcx_steps * l.eqcxb_nbl * 128 + l.eqcxb_nbl * 64 : 0);
-    l.eqsym_t = !l.use_eqcx ? 0 : l.l2 <= 9 ? 9 : l.l2 <= 17 ? 17 : l.l2 <= 25 ? 25 : 31;
+    // symmetric-form forward on the vector pipe: half the multiply-adds of the matrix product and no padding of the lag count
+    l.eqsym_t = l.use_eqcx ? (l.l2 <= 9 ? 9 : l.l2 <= 17 ? 17 : l.l2 <= 25 ? 25 : 31)
+                           : (l.use_eqcxb && l.l2 <= 65) ? (l.l2 <= 47 ? 47 : 65) : 0;
     l.o_eqsym = take(l.eqsym_t ? l.eqsym_t * (l.eqsym_t + 1) + 2 * l.eqsym_t : 0);
-    l.o_part_eqcxb = take(l.use_eqcxb ? (int64_t)l.nblk_eq * l.eqcxb_rec : 0);
-    l.o_tot_eqcxb = take(l.use_eqcxb ? l.eqcxb_rec : 0);
+    l.o_part_eqcxb = take((l.use_eqcxb && !l.eqb16) ? (int64_t)l.nblk_eq * l.eqcxb_rec : 0);
+    l.o_tot_eqcxb = take((l.use_eqcxb && !l.eqb16) ? l.eqcxb_rec : 0);
     {
         int64_t mx = l.rec_elbo;
         if (l.rec_eq > mx) mx = l.rec_eq;
@@ -250,6 +258,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
         if (l.use_cxb && l.S * l.cxb_rec > mx) mx = l.S * l.cxb_rec;
         if (4096 > mx) mx = 4096;
         if (l.use_eqcxb && l.eqcxb_rec > mx) mx = l.eqcxb_rec;
+        if (l.eqb16_rec > mx) mx = l.eqb16_rec;
         l.sumstage_stride = (int64_t)SUM_CHUNKS * mx;
         l.o_sumstage = take(3 * l.sumstage_stride);
     }
@@ -1843,9 +1852,9 @@ int v2vae_eq_bwd(const v2vae_problem* p, const float* y, const float* gxhat, voi
     if (rc) return rc;
     if (!y || !gxhat || !ws) return V2VAE_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (l.use_eqcx) {
-        launch_eq_bwd_cx(l, y, gxhat, (float*)ws, st);
-        return launch_status();
+    if (l.eqb16) {
+        rc = launch_eq_bwd_cx(l, y, gxhat, (float*)ws, st);
+        return rc ? rc : launch_status();
     }
     if (l.use_eqcxb) {
         rc = launch_eq_bwd_cxb(l, y, gxhat, (float*)ws, st);
@@ -1879,7 +1888,7 @@ int v2vae_finish_grads(const v2vae_problem* p, void* ws, const double* scal, con
     else if ((which & 1) && l.use_cxb) sum_sets_add(ss, w + l.o_part_cxb, l.S * l.cxb_rec, l.nblk_cxb, stage, w + l.o_tot_cxb);
     else if (which & 1) sum_sets_add(ss, w + l.o_part_elbo, l.rec_elbo, l.nblk_elbo, stage, w + l.o_tot_elbo);
     if (which & 2) sum_sets_add(ss, w + l.o_part_sym, l.rec_sym, l.nblk_sym, stage + l.sumstage_stride, w + l.o_tot_sym);
-    if ((which & 4) && l.use_eqcx) sum_sets_add(ss, w + l.o_part_eqcx, 2048, l.nblk_eq, stage + 2 * l.sumstage_stride, w + l.o_tot_eqcx);
+    if ((which & 4) && l.eqb16) sum_sets_add(ss, w + l.o_part_eqcx, l.eqb16_rec, l.nblk_eq, stage + 2 * l.sumstage_stride, w + l.o_tot_eqcx);
     else if ((which & 4) && l.use_eqcxb) sum_sets_add(ss, w + l.o_part_eqcxb, l.eqcxb_rec, l.nblk_eq, stage + 2 * l.sumstage_stride, w + l.o_tot_eqcxb);
     else if (which & 4) sum_sets_add(ss, w + l.o_part_eq, l.rec_eq, l.nblk_eq, stage + 2 * l.sumstage_stride, w + l.o_tot_eq);
     sum_sets_launch(ss, st);
@@ -1894,7 +1903,7 @@ int v2vae_finish_grads(const v2vae_problem* p, void* ws, const double* scal, con
     if ((which & 2) && g_scaling)
         hipLaunchKernelGGL(k_copy, dim3((l.rec_sym + NT - 1) / NT), dim3(NT), 0, st, (const float*)(w + l.o_tot_sym), g_scaling, l.rec_sym,
                            (which & 8) ? 1 : 0);
-    if ((which & 4) && l.use_eqcx) {
+    if ((which & 4) && l.eqb16) {
         launch_chain_equaliser_cx(l, w, g_k1, g_k2, st);
     } else if ((which & 4) && l.use_eqcxb) {
         launch_chain_equaliser_cxb(l, w, g_k1, g_k2, st);
@@ -2156,6 +2165,7 @@ int v2vae_fit_persistent(const v2vae_problem* p, const v2vae_fit_args* a, void* 
     l.cx_split = 0;
     l.use_cxb = 0;
     l.use_eqcx = 0;
+    l.eqb16 = 0;
     l.use_eqcxb = 0;
     l.eqcxb_fwd = 0;
     l.nblk_E = l.nblk_elbo;

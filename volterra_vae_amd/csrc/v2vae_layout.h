@@ -78,6 +78,9 @@ struct Lay {
     int64_t o_cxbA, o_cxbH, o_cxbc, o_part_cxb, o_tot_cxb;
     // matrix-core equaliser path
     int use_eqcx, eqcx_lk, eqcx_steps;
+    // backward of the complex equaliser on 16-lag blocks (k_eq_bwd_cx<NB16>): eqb16 = number of blocks (0: not used; l2 <= 79),
+    // records [2 planes][16 eqb16][16 eqb16] at o_part_eqcx / o_tot_eqcx
+    int eqb16, eqb16_rec, lds_eqb16;
     int64_t o_part_eqcx, o_tot_eqcx;
     // blocked matrix-core equaliser path (complex, 31 < l2 <= 95): lag rows in blocks of 32
     int use_eqcxb, eqcxb_fwd, eqcxb_nbl, eqcxb_rec, lds_eqcxb_fwd, lds_eqcxb_bwd;
