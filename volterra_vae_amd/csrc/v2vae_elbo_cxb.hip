@@ -13,6 +13,12 @@
 // global memory (L2-resident, every wave streams the same sequence) and are fetched ahead of the MFMA chains.
 // One workgroup = 4 waves, ONE per SIMD: the per-block register images of z, w, ... (6 x 8 x NB) and the NB^2 gradient
 // tiles need the full 512-register budget; the kernel is bound by its MFMA chains (504 per 32-window slab at NB = 3).
+//
+// Tap counts of the form 16 NB + 1 (L = 65 at two samples per symbol: 33) would waste a whole block row and column on one
+// tap.  The XT = 1 instances keep NB blocks on the matrix cores and carry tap e = 16 NB on the side: as a contraction index
+// it is ONE more MFMA step per output block (both streams of tap e fill the two k-slots); as an output row it is a dot
+// product per window on the vector ALU; its row and column of dE/dH are accumulated per lane in the transposed layout the
+// 16x16 MFMAs read.  Tables and records keep the stride 16 (NB + 1).
 #include <hip/hip_runtime.h>
 
 #include "v2vae_cx_common.h"
@@ -41,7 +47,7 @@ __device__ __forceinline__ float cxb_H(const Lay& l, const float* __restrict__ h
 
 __global__ __launch_bounds__(NT) void k_prep_cxb(Lay l, const float* __restrict__ h1, const float* __restrict__ h2,
                                                  float* __restrict__ ws) {
-    const int NB = l.cxb_nb, LEB = l.cxb_leb;
+    const int NB = l.cxb_nbk, LEB = l.cxb_leb;
     const int tid = blockIdx.x * NT + threadIdx.x, nth = gridDim.x * NT;
     for (int idx = tid; idx < l.S * 2 * LEB * LEB; idx += nth) {
         const int b = idx % LEB, a = (idx / LEB) % LEB, p = (idx / (LEB * LEB)) % 2, r = idx / (2 * LEB * LEB);
@@ -78,13 +84,27 @@ __global__ __launch_bounds__(NT) void k_prep_cxb(Lay l, const float* __restrict_
         }
         ws[l.o_cxbA + idx] = v;
     }
+    // extra-tap steps [r][xb][kind][64 lanes] behind the block-pair images: the two k-slots are the two streams of tap e = 16 NB;
+    // kind 0 = [[Hr, Hi], [-Hi, Hr]] (pass A), kind 1 = [[Hr, -Hi], [Hi, Hr]] (pass B)
+    if (l.cxb_xt) {
+        const int e = 16 * NB;
+        for (int idx = tid; idx < l.S * NB * 2 * 64; idx += nth) {
+            const int ln = idx & 63, kind = (idx >> 6) & 1, xb = (idx >> 7) % NB, r = (idx >> 7) / NB;
+            const int jj = ln & 31, ck = ln >> 5, cjj = jj >> 4, yo = 16 * xb + (jj & 15);
+            const float a = cxb_H(l, h2, r, 0, e, yo), b = cxb_H(l, h2, r, 1, e, yo);
+            float v;
+            if (kind == 0) v = ck == 0 ? (cjj == 0 ? a : b) : (cjj == 0 ? -b : a);
+            else v = ck == 0 ? (cjj == 0 ? a : -b) : (cjj == 0 ? b : a);
+            ws[l.o_cxbA + total + idx] = v;
+        }
+    }
 }
 
-template <int S, int NB>
+template <int S, int NB, int XT>
 __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restrict__ y, float* __restrict__ ws) {
     extern __shared__ __align__(16) float sm[];
-    constexpr int TWB = CXB_TWB, NU = CXB_NU, TP = CX_TP, NW = CXB_NW;
-    constexpr int LEB = 16 * NB, MS = TWB + LEB + 16, NSIG = 32 + LEB, NWP = NW / S;
+    constexpr int TWB = CXB_TWB, NU = CXB_NU, TP = XT ? CXB_TPX : CX_TP, NW = CXB_NW;
+    constexpr int LEB = 16 * (NB + XT), EX = 16 * NB, MS = TWB + LEB + 16, NSIG = 32 + LEB, NWP = NW / S;
     constexpr int REC = 2 * LEB * LEB + 4 * LEB;
     constexpr int STG = 11 * MS + 2 * S * TWB;
     float* s_stage = sm;                       // moments float4 [2][MS] | means [2][MS] | s [MS] | y' [2][S][TWB]
@@ -95,6 +115,7 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
     // per-wave parking area for two of the six per-(window, tap) arrays that live from pass A to pass B (|z|^2 + 4 T and
     // v_a - v_b): 48 registers per lane that would otherwise spill to scratch memory; [NW][2][NB * 8][64 lanes]
     float* s_park = s_rec + S * REC;
+    float* s_xe = s_park + NW * 2 * NB * 8 * 64;   // XT: [S][2][LEB] row e of the symmetrised kernel (Re, Im)
     __shared__ double dred[NW];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -112,6 +133,12 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
 
     for (int idx = tid; idx < S * 4 * LEB; idx += CXB_NT) s_c[idx] = ws[l.o_cxbc + idx];
     for (int idx = tid; idx < S * REC; idx += CXB_NT) s_rec[idx] = 0.f;
+    if (XT)
+        for (int idx = tid; idx < S * 2 * LEB; idx += CXB_NT) {
+            const int j = idx % LEB, rp = idx / LEB;
+            s_xe[idx] = ws[l.o_cxbH + ((size_t)rp * LEB + EX) * LEB + j];
+        }
+    const float* xe = s_xe + r * 2 * LEB;   // xe[j] = Re H(j, e), xe[LEB + j] = Im H(j, e)
     const float* __restrict__ Abase0 = ws + l.o_cxbA + (size_t)r * NB * NB * 40 * 64;
     const unsigned ulane = lane;
     const float* cst = s_c + r * 4 * LEB;
@@ -127,6 +154,13 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
 #pragma unroll
         for (int q = 0; q < 8; ++q) { ghr[a][q] = 0.f; ghi[a][q] = 0.f; gdr[a][q] = 0.f; gdi[a][q] = 0.f; }
     }
+    // extra tap e (XT): vector gradients, the (e, e) element, and row / column e of dE/dH in the transposed layout
+    // (lane = (tap lane & 15, window group lane >> 4))
+    float ghr_e = 0.f, ghi_e = 0.f, gdr_e = 0.f, gdi_e = 0.f, gee_r = 0.f, gee_i = 0.f;
+    float colr[NB], coli[NB], rowr[NB], rowi[NB];
+#pragma unroll
+    for (int a = 0; a < NB; ++a) { colr[a] = 0.f; coli[a] = 0.f; rowr[a] = 0.f; rowi[a] = 0.f; }
+    const float* __restrict__ Xbase0 = ws + l.o_cxbA + (size_t)S * NB * NB * 40 * 64 + (size_t)r * NB * 2 * 64;
     double Eacc = 0.0;
 #ifdef V2VAE_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
@@ -238,6 +272,17 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
             float abuf[2][16];   // two register sets, alternating by block pair: no copies
 #pragma unroll
             for (int s = 0; s < 16; ++s) abuf[0][s] = Abase[s * 64 + ulane];
+            const float* Xbase_generic = Xbase0;
+            asm volatile("" : "+s"(Xbase_generic));
+            const gfloat_p Xbase = (gfloat_p)Xbase_generic;
+            float xbufA[NB], xbufB[NB];
+            if (XT) {
+#pragma unroll
+                for (int xb = 0; xb < NB; ++xb) {
+                    xbufA[xb] = Xbase[(xb * 2 + 0) * 64 + ulane];
+                    xbufB[xb] = Xbase[(xb * 2 + 1) * 64 + ulane];
+                }
+            }
 #pragma unroll
             for (int xb = 0; xb < NB; ++xb) {
                 f32x16 U;
@@ -260,6 +305,7 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                     }
                     // (no (H.H) s product: the term of E that holds it and its variance gradient come from k_g2_cx)
                 }
+                if (XT) U = MFMA32(xbufA[xb], s_mu[h * MS + tsl + i + EX], U);
                 BSTAMP(1);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -295,10 +341,86 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
             q0 += __shfl_xor(q0, 32); q1 += __shfl_xor(q1, 32);
             sd0 += __shfl_xor(sd0, 32); sd1 += __shfl_xor(sd1, 32);
             vs += __shfl_xor(vs, 32);
+            // extra tap e: its row of H X as a dot product over all taps (each half of the wave takes the taps it holds, the
+            // halves are added), then the same per-(window, tap) algebra; both halves hold identical values from here on
+            float zp_e = 0.f, zq_e = 0.f, al_e = 0.f, be_e = 0.f, z2_e = 0.f, dv_e = 0.f, ma_e = 0.f, mb_e = 0.f;
+            if (XT) {
+                float pe = 0.f, qe = 0.f;
+#pragma unroll
+                for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int j = 16 * jb + cx_kk(q, h);
+                        const float ma = s_mu[tsl + i + j], mb = s_mu[MS + tsl + i + j];
+                        const float cr = xe[j], ci = xe[LEB + j];
+                        pe += ma * cr - mb * ci;
+                        qe += ma * ci + mb * cr;
+                    }
+                pe += __shfl_xor(pe, 32); qe += __shfl_xor(qe, 32);
+                const int slot = tsl + i + EX;
+                const float4 m4a = s_m4[slot], m4b = s_m4[MS + slot];
+                const float ma = m4a.x, va = m4a.y, ka = m4a.z, ga = m4a.w;
+                const float mb = m4b.x, vb = m4b.y, kb = m4b.z, gb = m4b.w;
+                pe += ma * xe[EX] - mb * xe[LEB + EX];
+                qe += ma * xe[LEB + EX] + mb * xe[EX];
+                const float hr = cst[EX], hi = cst[LEB + EX], dr = cst[2 * LEB + EX], di = cst[3 * LEB + EX];
+                const float zp = fmaf(2.f, pe, hr), zq = fmaf(2.f, qe, hi);
+                a0 += hr * ma - hi * mb;
+                a1 += hi * ma + hr * mb;
+                q0 += ma * pe - mb * qe;
+                q1 += ma * qe + mb * pe;
+                const float Sv = va + vb, dv = va - vb, gs = ga + gb;
+                sd0 = fmaf(dv, dr, sd0);
+                sd1 = fmaf(dv, di, sd1);
+                const float z2 = zp * zp + zq * zq;
+                const float ca = dr * zp + di * zq, cb = dr * zq - di * zp;
+                vs += Sv * z2 + 2.f * (ka * ca + kb * cb) + gs * (dr * dr + di * di);
+                al_e = 2.f * Sv * zp + 2.f * (ka * dr - kb * di);
+                be_e = 2.f * Sv * zq + 2.f * (ka * di + kb * dr);
+                zp_e = zp; zq_e = zq; z2_e = z2; dv_e = dv; ma_e = ma; mb_e = mb;
+                gdr_e += mo * (2.f * (ka * zp + kb * zq) + 2.f * gs * dr);
+                gdi_e += mo * (2.f * (ka * zq - kb * zp) + 2.f * gs * di);
+            }
             const float y0 = s_yw[(0 * S + r) * TWB + tsl + i], y1 = s_yw[(1 * S + r) * TWB + tsl + i];
             float e0 = a0 + q0 + sd0 - y0, e1 = a1 + q1 + sd1 - y1;
             if (own && h == 0) Eacc += (double)(e0 * e0 + e1 * e1 + vs);
             e0 *= mv; e1 *= mv;
+
+            // ---- extra tap e, second half: its row of H w from the registers, its anti-diagonal terms (window i -> symbol slot
+            // i + e, no reduction needed), vector gradients, and rho / sigma of tap e for row e of dE/dH
+            if (XT) {
+                float hwa = 0.f, hwb = 0.f;
+#pragma unroll
+                for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int j = 16 * jb + cx_kk(q, h);
+                        const float cr = xe[j], ci = xe[LEB + j];
+                        hwa += al[jb][q] * cr + be[jb][q] * ci;
+                        hwb += be[jb][q] * cr - al[jb][q] * ci;
+                    }
+                hwa += __shfl_xor(hwa, 32); hwb += __shfl_xor(hwb, 32);
+                hwa += al_e * xe[EX] + be_e * xe[LEB + EX];
+                hwb += be_e * xe[EX] - al_e * xe[LEB + EX];
+                const float dr = cst[2 * LEB + EX], di = cst[3 * LEB + EX];
+                const float ed = 2.f * (e0 * dr + e1 * di);
+                const float gr = 2.f * (e0 * ma_e + e1 * mb_e), gi = 2.f * (e1 * ma_e - e0 * mb_e);
+                ghr_e += mo * (gr + al_e);
+                ghi_e += mo * (gi + be_e);
+                gdr_e += mo * 2.f * e0 * dv_e;
+                gdi_e += mo * 2.f * e1 * dv_e;
+                const float Re = mo * (gr + 2.f * al_e), Se = mo * (gi + 2.f * be_e);
+                gee_r += Re * ma_e + Se * mb_e;
+                gee_i += Se * ma_e - Re * mb_e;
+                if (h == 0) {
+                    Pu[0 * NSIG + EX + i] += mv * (2.f * (e0 * zp_e + e1 * zq_e) + 2.f * hwa);
+                    Pu[1 * NSIG + EX + i] += mv * (2.f * (e1 * zp_e - e0 * zq_e) + 2.f * hwb);
+                    Pu[2 * NSIG + EX + i] += mv * (z2_e + ed);
+                    Pu[3 * NSIG + EX + i] += mv * (z2_e - ed);
+                    Tb[i * TP + 32] = Re;
+                    Tb[i * TP + 33] = Se;
+                }
+            }
 
             // ---- pass B: per output block H w, the anti-diagonal sums of the moment gradients, dE/dH
             float hbuf[2][16];
@@ -322,6 +444,7 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
 #pragma unroll
                     for (int s = 0; s < 16; ++s) HW = MFMA32(hbuf[pr & 1][s], s < 8 ? al[jb][s & 7] : be[jb][s & 7], HW);
                 }
+                if (XT) HW = MFMA32(xbufB[xb], h == 0 ? al_e : be_e, HW);
                 BSTAMP(3);
                 // anti-diagonal sums (symbol = window + tap) of the gradients of means (round 0) and variances (round 1), by
                 // lane shifts inside the wave (no LDS round trip); the partial of this tap block is added to the slab's record.
@@ -376,6 +499,15 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                         ar[st] = Tb[(4 * st + kq) * TP + xa];
                         as[st] = Tb[(4 * st + kq) * TP + 16 + xa];
                     }
+                    if (XT) {   // column e of dE/dH: this lane's share of sum_w (rho, sigma)(w, x) mu(w + e)
+#pragma unroll
+                        for (int st = 0; st < 8; ++st) {
+                            const int w = tsl + 4 * st + kq + EX;
+                            const float mae = s_mu[w], mbe = s_mu[MS + w];
+                            colr[xb] += ar[st] * mae + as[st] * mbe;
+                            coli[xb] += as[st] * mae - ar[st] * mbe;
+                        }
+                    }
 #pragma unroll
                     for (int jb = 0; jb < NB; ++jb) {
         #pragma unroll
@@ -386,6 +518,11 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                             Gr[xb][jb] = MFMA16(as[st], mb, Gr[xb][jb]);
                             Gi[xb][jb] = MFMA16(as[st], ma, Gi[xb][jb]);
                             Gi[xb][jb] = MFMA16(-ar[st], mb, Gi[xb][jb]);
+                            if (XT && xb == 0) {   // row e of dE/dH, once per slab: sum_w (rho, sigma)(w, e) mu(w + j)
+                                const float Re = Tb[(4 * st + kq) * TP + 32], Se = Tb[(4 * st + kq) * TP + 33];
+                                rowr[jb] += Re * ma + Se * mb;
+                                rowi[jb] += Se * ma - Re * mb;
+                            }
                         }
                     }
                 }
@@ -459,6 +596,32 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                     }
                 }
             }
+            if (XT) {
+#pragma unroll
+                for (int xb = 0; xb < NB; ++xb) {
+                    float c0 = colr[xb], c1 = coli[xb], r0 = rowr[xb], r1 = rowi[xb];
+                    c0 += __shfl_xor(c0, 16); c1 += __shfl_xor(c1, 16); r0 += __shfl_xor(r0, 16); r1 += __shfl_xor(r1, 16);
+                    c0 += __shfl_xor(c0, 32); c1 += __shfl_xor(c1, 32); r0 += __shfl_xor(r0, 32); r1 += __shfl_xor(r1, 32);
+                    if (lane < 16) {
+                        const int x = 16 * xb + lane;
+                        img[x * LEB + EX] += c0;
+                        img[(LEB + x) * LEB + EX] += c1;
+                        img[EX * LEB + x] += r0;
+                        img[(LEB + EX) * LEB + x] += r1;
+                    }
+                }
+                float v[6] = {ghr_e, ghi_e, gdr_e, gdi_e, gee_r, gee_i};
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+#pragma unroll
+                    for (int off = 1; off < 32; off <<= 1) v[k] += __shfl_xor(v[k], off);
+                if (lane == 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) img[2 * LEB * LEB + k * LEB + EX] += v[k];
+                    img[EX * LEB + EX] += v[4];
+                    img[(LEB + EX) * LEB + EX] += v[5];
+                }
+            }
         }
         __syncthreads();
     }
@@ -525,15 +688,18 @@ void launch_prep_cxb(const Lay& l, const float* h1, const float* h2, float* ws, 
 
 int launch_elbo_cxb(const Lay& l, const float* y, float* ws, hipStream_t st) {
     const int lds = l.lds_cxb;
-#define V2VAE_LAUNCH_CXB(SS, NBB)                                                                                          \
+#define V2VAE_LAUNCH_CXB(SS, NBB, XTT)                                                                                        \
     do {                                                                                                                   \
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_elbo_cxb<SS, NBB>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_elbo_cxb<SS, NBB, XTT>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 lds) != hipSuccess)                                                                        \
             return V2VAE_ELAUNCH;                                                                                          \
-        hipLaunchKernelGGL((k_elbo_cxb<SS, NBB>), dim3(l.nblk_cxb), dim3(CXB_NT), lds, st, l, y, ws);                       \
+        hipLaunchKernelGGL((k_elbo_cxb<SS, NBB, XTT>), dim3(l.nblk_cxb), dim3(CXB_NT), lds, st, l, y, ws);                  \
     } while (0)
-    if (l.cxb_nb == 2) { if (l.S == 1) V2VAE_LAUNCH_CXB(1, 2); else V2VAE_LAUNCH_CXB(2, 2); }
-    else { if (l.S == 1) V2VAE_LAUNCH_CXB(1, 3); else V2VAE_LAUNCH_CXB(2, 3); }
+    if (l.cxb_xt) {
+        if (l.cxb_nbk == 1) { if (l.S == 1) V2VAE_LAUNCH_CXB(1, 1, 1); else V2VAE_LAUNCH_CXB(2, 1, 1); }
+        else { if (l.S == 1) V2VAE_LAUNCH_CXB(1, 2, 1); else V2VAE_LAUNCH_CXB(2, 2, 1); }
+    } else if (l.cxb_nb == 2) { if (l.S == 1) V2VAE_LAUNCH_CXB(1, 2, 0); else V2VAE_LAUNCH_CXB(2, 2, 0); }
+    else { if (l.S == 1) V2VAE_LAUNCH_CXB(1, 3, 0); else V2VAE_LAUNCH_CXB(2, 3, 0); }
 #undef V2VAE_LAUNCH_CXB
     return V2VAE_OK;
 }

@@ -155,6 +155,8 @@ int make_layout(const v2vae_problem* p, Lay* out) {
         // blocked variant for longer channels
         l.use_cxb = (l.mode == 1 && l.LE > 16 && l.LE <= 48 && l.S <= 2 && !(l.flags & V2VAE_FLAG_GENERIC)) ? 1 : 0;
         l.cxb_nb = (l.LE + 15) / 16;
+        l.cxb_xt = (l.LE % 16 == 1 && !(l.flags & V2VAE_FLAG_ELBO_TILES)) ? 1 : 0;
+        l.cxb_nbk = l.cxb_nb - l.cxb_xt;
         l.cxb_leb = 16 * l.cxb_nb;
         l.cxb_rec = 2 * l.cxb_leb * l.cxb_leb + 4 * l.cxb_leb;
         {
@@ -162,8 +164,9 @@ int make_layout(const v2vae_problem* p, Lay* out) {
             l.ntile_cxb = l.use_cxb ? (int)((l.own_cnt + tsb - 1) / tsb) : 0;
             l.nblk_cxb = l.ntile_cxb < CX_BLOCKS ? l.ntile_cxb : CX_BLOCKS;
             const int ms = CXB_TWB + l.cxb_leb + 16, nsig = 32 + l.cxb_leb;
-            l.lds_cxb = ((11 * ms + 2 * l.S * CXB_TWB) + l.S * 4 * l.cxb_leb + 4 * 32 * CX_TP +
-                         l.S * (CXB_TWB / 32) * 4 * nsig + l.S * l.cxb_rec + 4 * 2 * l.cxb_nb * 8 * 64) * 4;
+            l.lds_cxb = ((11 * ms + 2 * l.S * CXB_TWB) + l.S * 4 * l.cxb_leb + 4 * 32 * (l.cxb_xt ? CXB_TPX : CX_TP) +
+                         l.S * (CXB_TWB / 32) * 4 * nsig + l.S * l.cxb_rec + 4 * 2 * l.cxb_nbk * 8 * 64 +
+                         (l.cxb_xt ? l.S * 2 * l.cxb_leb : 0)) * 4;
         }
         l.nblk_E = l.use_cx ? l.nblk_cx + G2_NE : (l.use_cxb ? l.nblk_cxb + G2_NE : l.nblk_elbo);   // + 1: the lagged-product term of E (k_g2_cx)
         if (!l.use_cx && !l.use_cxb && !generic_elbo_ok) return V2VAE_ESIZE;

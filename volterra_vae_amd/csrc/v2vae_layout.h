@@ -30,6 +30,7 @@ constexpr int CX_IMG = 2112;         // floats of the block-tile kernel's LDS im
 constexpr int SUM_CHUNKS = 32;       // first-stage groups of the two-stage partial-record sums
 constexpr int CX_BLOCKS = 256;       // one workgroup per CU (the LDS image takes most of a CU)
 constexpr int CXB_TWB = 256;         // windows per phase per block tile of the blocked kernel
+constexpr int CXB_TPX = 35;          // row pitch of its transposing buffer when an extra tap rides along (columns 32, 33)
 constexpr int CX_MAXLAG = 48;        // lagged products kept for sum s s^T (largest blocked tap count)
 constexpr int G2C_D = 4 + 2 * (2 * CX_MAXLAG + 8);   // offset of the real coefficients D[lag] in the table at Lay::o_g2c
 constexpr int G2C_FLOATS = G2C_D + 2 * CX_MAXLAG + 8;
@@ -74,7 +75,9 @@ struct Lay {
     int cx_split;
     int64_t cx_rl, o_gpk;
     // blocked matrix-core ELBO path (complex, 16 < active taps per phase <= 48): taps in blocks of 16
-    int use_cxb, cxb_nb, cxb_leb, ntile_cxb, nblk_cxb, lds_cxb, cxb_rec;
+    // cxb_nb blocks give the stride cxb_leb of tables and records; the kernel runs cxb_nbk blocks on the matrix cores plus cxb_xt
+    // (0 or 1) extra tap on the side (tap counts 16 cxb_nbk + 1), else cxb_nbk = cxb_nb
+    int use_cxb, cxb_nb, cxb_nbk, cxb_xt, cxb_leb, ntile_cxb, nblk_cxb, lds_cxb, cxb_rec;
     int64_t o_cxbA, o_cxbH, o_cxbc, o_part_cxb, o_tot_cxb;
     // matrix-core equaliser path
     int use_eqcx, eqcx_lk, eqcx_steps;
