@@ -36,6 +36,7 @@ ws = plan.ws
 nb = 256; NW = int(os.environ.get("NW", "4"))
 raw = ws[lay_off:lay_off + nb * NW * 8 * 2].cpu().numpy().view(np.uint64).reshape(nb, NW, 8)
 tot = raw.sum(axis=2, keepdims=True).astype(np.float64)
-print("mean cycles per wave per phase:", raw.mean(axis=(0, 1)))
+np.set_printoptions(linewidth=200, suppress=True)
+print("mean cycles per wave per phase:", raw.mean(axis=(0, 1)).round(0))
 print("share:", (raw / tot).mean(axis=(0, 1)))
 print("total per wave (cycles):", tot.mean())

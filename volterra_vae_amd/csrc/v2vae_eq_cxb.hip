@@ -328,24 +328,50 @@ int launch_prep_eqcxb(const Lay& l, const float* k1, const float* k2, float* ws,
 // two packed FMAs.
 typedef float eq_f2 __attribute__((ext_vector_type(2)));
 
+// Kernels of up to 31 lags take NSY = 2 symbols per thread (a tile of 512 symbols): every kernel entry fetched serves both, which
+// halves the scalar-load waits the instruction stream is bound by.
+// acc += k * y for complex numbers held as (Re, Im) register pairs: two packed FMAs on the pairs as they are -- the first takes
+// Re k for both halves (op_sel), the second Im k against (-Im y, Re y) (op_sel swaps the halves of y, neg_lo negates the low one).
+// k comes straight from the scalar registers a scalar load filled (_s) or from vector registers (_v); written as inline assembly
+// because the compiler builds the broadcast and the rotated pair with scalar moves instead (two to four per entry).
+__device__ __forceinline__ void eq_cmac_s(eq_f2& acc, unsigned long long k, eq_f2 y) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "+v"(acc) : "s"(k), "v"(y));
+}
+__device__ __forceinline__ void eq_cmac_v(eq_f2& acc, eq_f2 k, eq_f2 y) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "+v"(acc) : "v"(k), "v"(y));
+}
+
 template <int T>
-__global__ __launch_bounds__(NT, T <= 31 ? 4 : 2) void k_eq_fwd_sym(Lay l, const float* __restrict__ y, const float* __restrict__ ws,
-                                                      float* __restrict__ xhat) {
+__global__ __launch_bounds__(NT, T <= 25 ? 4 : T <= 31 ? 3 : 2) void k_eq_fwd_sym(Lay l, const float* __restrict__ y,
+                                                                              const float* __restrict__ ws, float* __restrict__ xhat) {
     extern __shared__ float sm[];
     float* tile = sm;
+    constexpr int NSY = T <= 31 ? 2 : 1, TB = NSY * EQ_TB;
     const int tid = threadIdx.x;
-    const float* __restrict__ tab = ws + l.o_eqsym;
+    const float* tab0 = ws + l.o_eqsym;
     constexpr int NP = T * (T + 1) / 2;
     const int64_t sym_hi = l.sym_lo + l.sym_cnt;
-    const int64_t ntile = (l.sym_cnt + EQ_TB - 1) / EQ_TB;
+    const int64_t ntile = (l.sym_cnt + TB - 1) / TB;
+    const int tlen = l.tile_len + (NSY - 1) * EQ_TB * l.S;
     for (int64_t t = blockIdx.x; t < ntile; t += gridDim.x) {
-        const int64_t b0 = l.sym_lo + t * EQ_TB;
+        const int64_t b0 = l.sym_lo + t * TB;
+        // The table base is re-declared opaque (a scalar register pair) per tile: the table does not depend on the tile, and
+        // hoisted out of this loop its T (T + 3) / 2 scalar loads would be held in (and spilled from) scalar registers.  The
+        // opaque copy is cast to the constant address space so that the loads stay scalar loads; entries are (Re, Im) pairs.
+        typedef const unsigned long long __attribute__((address_space(4))) * ctab_p;
+        const float* tab_generic = tab0;
+        asm volatile("" : "+s"(tab_generic));
+        const ctab_p tab = (ctab_p)tab_generic;
         __syncthreads();
         {
             const int64_t g0 = b0 * l.S - l.hl;
-            const int n = l.ns * l.tile_len;
+            const int n = l.ns * tlen;
             for (int idx = tid; idx < n; idx += NT) {
-                const int c = idx >= l.tile_len ? 1 : 0, i = idx - c * l.tile_len;
+                const int c = idx >= tlen ? 1 : 0, i = idx - c * tlen;
                 const int64_t g = g0 + i;
                 float v = 0.f;
                 if (g >= 0 && g < l.n_glob) {
@@ -356,32 +382,44 @@ __global__ __launch_bounds__(NT, T <= 31 ? 4 : 2) void k_eq_fwd_sym(Lay l, const
             }
         }
         __syncthreads();
-        const int base = tid * l.S + l.hl + l.p2;
-        eq_f2 yv[T];
+        eq_f2 yv[NSY][T];
 #pragma unroll
-        for (int x = 0; x < T; ++x) {
-            const bool in = x < l.l2;
-            yv[x] = in ? eq_f2{tile[base - x], tile[l.tile_len + base - x]} : eq_f2{0.f, 0.f};
+        for (int n = 0; n < NSY; ++n) {
+            const int base = (tid + n * EQ_TB) * l.S + l.hl + l.p2;
+#pragma unroll
+            for (int x = 0; x < T; ++x) {
+                const bool in = x < l.l2;
+                yv[n][x] = in ? eq_f2{tile[base - x], tile[tlen + base - x]} : eq_f2{0.f, 0.f};
+            }
         }
-        eq_f2 out = {0.f, 0.f};
+        eq_f2 out[NSY];
+#pragma unroll
+        for (int n = 0; n < NSY; ++n) out[n] = eq_f2{0.f, 0.f};
         int p = 0;
 #pragma unroll
         for (int a = 0; a < T; ++a) {
-            const eq_f2 k1w = {tab[2 * (NP + a)], tab[2 * (NP + a) + 1]};
-            eq_f2 u = k1w;
+            eq_f2 u[NSY];
+            {
+                const unsigned long long k1w = tab[NP + a];
+#pragma unroll
+                for (int n = 0; n < NSY; ++n) u[n] = __builtin_bit_cast(eq_f2, k1w);
+            }
 #pragma unroll
             for (int b = a; b < T; ++b, ++p) {
-                const eq_f2 K = {tab[2 * p], tab[2 * p + 1]};
-                u += K.xx * yv[b];
-                u += eq_f2{-K.y, K.y} * yv[b].yx;
+                const unsigned long long K = tab[p];
+#pragma unroll
+                for (int n = 0; n < NSY; ++n) eq_cmac_s(u[n], K, yv[n][b]);
             }
-            out += u.xx * yv[a];
-            out += eq_f2{-u.y, u.y} * yv[a].yx;
+#pragma unroll
+            for (int n = 0; n < NSY; ++n) eq_cmac_v(out[n], u[n], yv[n][a]);
         }
-        const int64_t b = b0 + tid;
-        if (b < sym_hi) {
-            xhat[b - l.sym_lo] = out.x;
-            xhat[l.sym_cnt + (b - l.sym_lo)] = out.y;
+#pragma unroll
+        for (int n = 0; n < NSY; ++n) {
+            const int64_t b = b0 + tid + n * EQ_TB;
+            if (b < sym_hi) {
+                xhat[b - l.sym_lo] = out[n].x;
+                xhat[l.sym_cnt + (b - l.sym_lo)] = out[n].y;
+            }
         }
     }
 }
@@ -396,9 +434,11 @@ static int eqcxb_allow_lds(K kernel, int bytes) {
 int launch_eq_fwd_cxb(const Lay& l, const float* y, const float* ws, float* xhat, hipStream_t st) {
     int nblk = (int)((l.sym_cnt + EQ_TB - 1) / EQ_TB);
     if (l.eqsym_t && !(l.flags & V2VAE_FLAG_EQ_MFMA_FWD)) {
-        const int per_cu = l.eqsym_t <= 31 ? 4 : 2;                   // resident workgroups per CU (launch bounds)
+        const int per_cu = l.eqsym_t <= 25 ? 4 : l.eqsym_t <= 31 ? 3 : 2;   // resident workgroups per CU (launch bounds)
+        const int nsy = l.eqsym_t <= 31 ? 2 : 1;                            // symbols per thread
+        nblk = (nblk + nsy - 1) / nsy;
         const int nb = nblk < per_cu * CX_BLOCKS ? nblk : per_cu * CX_BLOCKS;
-        const int lds = l.ns * l.tile_len * 4;
+        const int lds = l.ns * (l.tile_len + (nsy - 1) * EQ_TB * l.S) * 4;
         if (l.eqsym_t == 9) hipLaunchKernelGGL(k_eq_fwd_sym<9>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat);
         else if (l.eqsym_t == 17) hipLaunchKernelGGL(k_eq_fwd_sym<17>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat);
         else if (l.eqsym_t == 25) hipLaunchKernelGGL(k_eq_fwd_sym<25>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat);
