@@ -34,13 +34,20 @@ __device__ __forceinline__ void eqcx_load_tile(const Lay& l, const float* __rest
 }
 
 // NB16 = blocks of 16 lag rows (lags 0 .. l2, the ones column at index l2 included): 2 for up to 31 lags, ... 5 for up to 79.
-template <int NB16>
+// SS = samples per symbol when it is 1 or 2 (the sample offsets of the unrolled symbol loop are then instruction immediates),
+// 0 = read from the layout.
+// LDS: sample tile [ns][tile_len] | per-symbol gradient combinations, 4-vectors [EQ_TB] and a plane [EQ_TB] | ones [64 S] | zeros [64 S].
+template <int NB16, int SS>
 __global__ __launch_bounds__(NT, NB16 <= 3 ? 4 : 2) void k_eq_bwd_cx(Lay l, const float* __restrict__ y, const float* __restrict__ gx,
                                                                   float* __restrict__ ws) {
     constexpr int NBLK = NB16 * (NB16 + 1) / 2, LD = 16 * NB16;
-    extern __shared__ float sm[];
+    extern __shared__ __align__(16) float sm[];
+    const int S = SS ? SS : l.S;
     float* tile = sm;
-    float* gt = tile + l.ns * l.tile_len;  // [2][EQ_TB]
+    const int ntl = (l.ns * l.tile_len + 3) & ~3;
+    f32x4* g4 = reinterpret_cast<f32x4*>(sm + ntl);   // (g0 + g1, g1 - g0, g1, -g0) per symbol of the tile
+    float* ng1 = sm + ntl + 4 * EQ_TB;                 // -g1
+    const int o_ones = ntl + 5 * EQ_TB, o_zeros = o_ones + 64 * S;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int i16 = lane & 15, kq = lane >> 4;
     // Both gradient planes are symmetric in the lag pair, so only the upper-triangular 16x16 blocks (ib <= jb) are
@@ -49,20 +56,27 @@ __global__ __launch_bounds__(NT, NB16 <= 3 ? 4 : 2) void k_eq_bwd_cx(Lay l, cons
     // instead of four:  K1 = (rho + sigma)^T Ya,  K2 = -rho^T (Ya + Yb),  K3 = sigma^T (Ya - Yb);  dK_r = K1 - K3, dK_i = K1 + K2.
     // The sums are linear, so K1, K2, K3 are accumulated over all symbols and combined once at the end.  The ones column
     // (first-order gradient) sits in Ya only; its Yb entry is zero in all three operands.
+    // f32 MFMAs and vector instructions do not overlap on this part, so the operand preparation is kept to six vector
+    // instructions per (k-step, block): the three row operands are linear in (Ya, Yb) with per-symbol coefficients that are formed
+    // once per tile, and the lanes of the ones column (and beyond) read constant 1 / 0 samples from LDS instead of being patched.
     f32x4 A[NBLK], B[NBLK], C[NBLK];
 #pragma unroll
     for (int q = 0; q < NBLK; ++q)
 #pragma unroll
         for (int g = 0; g < 4; ++g) { A[q][g] = 0.f; B[q][g] = 0.f; C[q][g] = 0.f; }
-    const float* tr = tile;
-    const float* ti = tile + l.tile_len;
-    int jc[NB16];
-    bool ones[NB16];
+    for (int idx = tid; idx < 128 * S; idx += NT) sm[o_ones + idx] = idx < 64 * S ? 1.f : 0.f;
+    // per-lane sample positions of symbol (wave base + kq) for each block; rows / columns from l2 on read the constants (their rows
+    // are never read back, column l2 is the ones column)
+    const float* pa[NB16];
+    const float* pb[NB16];
+    {
+        const int base0 = (wv * 64 + kq) * S + l.hl + l.p2;
 #pragma unroll
-    for (int ib = 0; ib < NB16; ++ib) {
-        const int j = 16 * ib + i16;
-        ones[ib] = (j == l.l2);
-        jc[ib] = j <= l.l2 ? j : l.l2;   // rows / columns beyond l2 are never read back
+        for (int ib = 0; ib < NB16; ++ib) {
+            const int j = 16 * ib + i16;
+            pa[ib] = sm + (j >= l.l2 ? o_ones : base0 - j);
+            pb[ib] = sm + (j >= l.l2 ? o_zeros : l.tile_len + base0 - j);
+        }
     }
     for (int t = blockIdx.x; t < l.ntile_eq; t += gridDim.x) {
         const int64_t b0 = l.own_lo + (int64_t)t * EQ_TB;
@@ -70,29 +84,28 @@ __global__ __launch_bounds__(NT, NB16 <= 3 ? 4 : 2) void k_eq_bwd_cx(Lay l, cons
         const int nbs = rem < EQ_TB ? (int)rem : EQ_TB;
         __syncthreads();
         eqcx_load_tile(l, y, b0 * l.S - l.hl, tile);
-        for (int idx = tid; idx < 2 * EQ_TB; idx += NT) {
-            const int o = idx / EQ_TB, i = idx - o * EQ_TB;
-            gt[idx] = i < nbs ? gx[(int64_t)o * l.sym_cnt + (b0 + i - l.sym_lo)] : 0.f;
+        {   // EQ_TB == NT: one symbol per thread
+            const float g0 = tid < nbs ? gx[b0 + tid - l.sym_lo] : 0.f;
+            const float g1 = tid < nbs ? gx[l.sym_cnt + (b0 + tid - l.sym_lo)] : 0.f;
+            g4[tid] = f32x4{g0 + g1, g1 - g0, g1, -g0};
+            ng1[tid] = -g1;
         }
         __syncthreads();
         const int wbase = wv * 64;
-#pragma unroll(NB16 <= 2 ? 2 : 1)
+#pragma unroll((NB16 <= 2 && SS > 0) ? 16 : 2)
         for (int s = 0; s < 16; ++s) {
-            const int bloc = wbase + 4 * s + kq;
-            const int base = bloc * l.S + l.hl + l.p2;
-            const float g0 = gt[bloc], g1 = gt[EQ_TB + bloc];
+            const f32x4 gg = g4[wbase + 4 * s + kq];
+            const float n1 = ng1[wbase + 4 * s + kq];
             float rs[NB16], nrho[NB16], sig[NB16], ca[NB16], cs[NB16], cd[NB16];
 #pragma unroll
             for (int ib = 0; ib < NB16; ++ib) {
-                const float xa = tr[base - jc[ib]], xb = ti[base - jc[ib]];
-                const float rho = g0 * xa + g1 * xb;
-                sig[ib] = g1 * xa - g0 * xb;
-                nrho[ib] = -rho;
-                rs[ib] = rho + sig[ib];
-                ca[ib] = ones[ib] ? 1.f : xa;
-                const float cb = ones[ib] ? 0.f : xb;
-                cs[ib] = ca[ib] + cb;
-                cd[ib] = ca[ib] - cb;
+                const float xa = pa[ib][4 * s * S], xb = pb[ib][4 * s * S];
+                rs[ib] = gg.x * xa + gg.y * xb;      // rho + sigma
+                sig[ib] = gg.z * xa + gg.w * xb;     // g1 Ya - g0 Yb
+                nrho[ib] = gg.w * xa + n1 * xb;      // -(g0 Ya + g1 Yb)
+                ca[ib] = xa;
+                cs[ib] = xa + xb;
+                cd[ib] = xa - xb;
             }
 #pragma unroll
             for (int ib = 0; ib < NB16; ++ib)
@@ -157,12 +170,18 @@ __global__ __launch_bounds__(NT) void k_chain_equaliser_cx(Lay l, const float* _
 
 int launch_eq_bwd_cx(const Lay& l, const float* y, const float* gx, float* ws, hipStream_t st) {
     const int lds = l.lds_eqb16;
-#define V2VAE_LAUNCH_EQB16(NB)                                                                                                   \
+#define V2VAE_LAUNCH_EQB16_S(NB, SS)                                                                                             \
     do {                                                                                                                         \
-        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k_eq_bwd_cx<NB>),                                \
+        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k_eq_bwd_cx<NB, SS>),                            \
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)               \
             return V2VAE_ELAUNCH;                                                                                                \
-        hipLaunchKernelGGL(k_eq_bwd_cx<NB>, dim3(l.nblk_eq), dim3(NT), lds, st, l, y, gx, ws);                                    \
+        hipLaunchKernelGGL((k_eq_bwd_cx<NB, SS>), dim3(l.nblk_eq), dim3(NT), lds, st, l, y, gx, ws);                              \
+    } while (0)
+#define V2VAE_LAUNCH_EQB16(NB)                       \
+    do {                                             \
+        if (l.S == 1) V2VAE_LAUNCH_EQB16_S(NB, 1);   \
+        else if (l.S == 2) V2VAE_LAUNCH_EQB16_S(NB, 2); \
+        else V2VAE_LAUNCH_EQB16_S(NB, 0);            \
     } while (0)
     switch (l.eqb16) {
         case 1: V2VAE_LAUNCH_EQB16(1); break;
@@ -173,6 +192,7 @@ int launch_eq_bwd_cx(const Lay& l, const float* y, const float* gx, float* ws, h
         default: return V2VAE_ESIZE;
     }
 #undef V2VAE_LAUNCH_EQB16
+#undef V2VAE_LAUNCH_EQB16_S
     return V2VAE_OK;
 }
 

@@ -196,7 +196,8 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     l.eqb16 = (l.use_eqcx || (l.use_eqcxb && l.l2 <= 79)) ? (l.l2 + 1 + 15) / 16 : 0;
     l.eqb16_rec = 2 * (16 * l.eqb16) * (16 * l.eqb16);
     {
-        const int64_t a = l.lds_eq / 4, b = l.eqb16_rec;
+        // sample tile, per-symbol gradient combinations (5 per symbol), constant ones / zeros (64 S each); afterwards the record
+        const int64_t a = (((int64_t)l.ns * l.tile_len + 3) & ~(int64_t)3) + 5 * EQ_TB + 128 * l.S, b = l.eqb16_rec;
         l.lds_eqb16 = (int)((a > b ? a : b) * 4);
     }
     if (l.eqb16) l.nblk_eq = l.eqb16 <= 3 ? (l.ntile_eq < 1024 ? l.ntile_eq : 1024) : (l.ntile_eq < 512 ? l.ntile_eq : 512);
