@@ -563,46 +563,53 @@ __device__ __forceinline__ double xhat_full(const Lay& l, const float* __restric
 // ------------------------------------------------------------------------------------------
 // soft demapping, moments, KL
 // ------------------------------------------------------------------------------------------
-template <int CB>
+// EX: exactly CB levels per stream and two streams, both known at compile time (no bounds checks, levels in registers)
+template <int CB, bool EX = false>
 __device__ __forceinline__ void d_demap_moments(const GridCtx gc, Lay l, const float* __restrict__ xhat, const float* __restrict__ levels,
                                                       const float* __restrict__ prior, const float* __restrict__ scaling,
                                                       const float* __restrict__ noise_var, float* __restrict__ ws,
                                                       float* __restrict__ q_out) {
     __shared__ double red[NT / 64];
+    const int C = EX ? CB : l.C, NS = EX ? 2 : l.ns;
     const float nv = noise_var[0];
     float* __restrict__ mom = ws + l.o_mom;
     double kl = 0.0;
     double inv_den[2][MAX_C];
-    posterior_temperatures<CB>(scaling, l.C, nv, inv_den[0]);
-    posterior_temperatures<CB>(scaling + (l.ns - 1) * l.C, l.C, nv, inv_den[1]);
+    posterior_temperatures<CB>(scaling, C, nv, inv_den[0]);
+    posterior_temperatures<CB>(scaling + (NS - 1) * C, C, nv, inv_den[1]);
     float inv_pr[2][MAX_C];  // 1 / prior, once per thread instead of a division per symbol and level
+    float lvr[2][MAX_C];     // the levels, in registers
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int k = 0; k < CB; ++k) inv_pr[c][k] = (c < l.ns && k < l.C) ? 1.f / prior[c * l.C + k] : 0.f;
+        for (int k = 0; k < CB; ++k) {
+            const bool in = c < NS && k < C;
+            inv_pr[c][k] = in ? 1.f / prior[c * C + k] : 0.f;
+            lvr[c][k] = in ? levels[c * C + k] : 0.f;
+        }
     const int64_t stride = (int64_t)gc.nb * NT;
     float nx[2] = {0.f, 0.f};   // the next symbol's samples, requested one iteration ahead
     {
         const int64_t i0 = (int64_t)gc.bid * NT + threadIdx.x;
-        if (i0 < l.sym_cnt) { nx[0] = xhat[i0]; if (l.ns > 1) nx[1] = xhat[l.sym_cnt + i0]; }
+        if (i0 < l.sym_cnt) { nx[0] = xhat[i0]; if (NS > 1) nx[1] = xhat[l.sym_cnt + i0]; }
     }
     for (int64_t i = (int64_t)gc.bid * NT + threadIdx.x; i < l.sym_cnt; i += stride) {
         const int64_t b = l.sym_lo + i;
         const bool in_kl = b >= l.kl_lo && b < l.kl_hi && b >= l.own_lo && b < l.own_lo + l.own_cnt;
         const float cx[2] = {nx[0], nx[1]};
-        if (i + stride < l.sym_cnt) { nx[0] = xhat[i + stride]; if (l.ns > 1) nx[1] = xhat[l.sym_cnt + i + stride]; }
+        if (i + stride < l.sym_cnt) { nx[0] = xhat[i + stride]; if (NS > 1) nx[1] = xhat[l.sym_cnt + i + stride]; }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            if (c >= l.ns) break;
+            if (c >= NS) break;
             Posterior p;
-            posterior<CB>(xhat_full(l, ws, i, cx[c]), levels + c * l.C, inv_den[c], l.C, p);
+            posterior<CB, EX>(xhat_full(l, ws, i, cx[c]), lvr[c], inv_den[c], C, p);
             float* m = mom + (int64_t)c * 4 * l.sym_cnt + i;
             m[0] = p.mu; m[l.sym_cnt] = p.var; m[2 * l.sym_cnt] = p.kap; m[3 * l.sym_cnt] = p.gam;
             float klb = 0.f;
 #pragma unroll
             for (int k = 0; k < CB; ++k)
-                if (k < l.C) {
-                    if (q_out) q_out[((int64_t)c * l.C + k) * l.sym_cnt + i] = p.q[k];
+                if (k < C) {
+                    if (q_out) q_out[((int64_t)c * C + k) * l.sym_cnt + i] = p.q[k];
                     klb += p.q[k] * __logf(fmaf(p.q[k], inv_pr[c][k], 1e-12f));  // argument >= 1e-12: the hardware log is exact enough
                 }
             if (in_kl) kl += (double)klb;
@@ -612,12 +619,12 @@ __device__ __forceinline__ void d_demap_moments(const GridCtx gc, Lay l, const f
     if (threadIdx.x == 0) reinterpret_cast<double*>(ws + l.o_KLpart)[gc.bid] = s;
 }
 
-template <int CB>
+template <int CB, bool EX>
 __global__ __launch_bounds__(NT, CB <= 4 ? 4 : CB <= 8 ? 2 : 1) void k_demap_moments(Lay l, const float* __restrict__ xhat, const float* __restrict__ levels,
                                                       const float* __restrict__ prior, const float* __restrict__ scaling,
                                                       const float* __restrict__ noise_var, float* __restrict__ ws,
                                                       float* __restrict__ q_out) {
-    d_demap_moments<CB>(GridCtx{(int)blockIdx.x, (int)gridDim.x}, l, xhat, levels, prior, scaling, noise_var, ws, q_out);
+    d_demap_moments<CB, EX>(GridCtx{(int)blockIdx.x, (int)gridDim.x}, l, xhat, levels, prior, scaling, noise_var, ws, q_out);
 }
 
 __global__ __launch_bounds__(NT) void k_decide(Lay l, const float* __restrict__ xhat, const float* __restrict__ levels,
@@ -641,13 +648,15 @@ __global__ __launch_bounds__(NT) void k_decide(Lay l, const float* __restrict__ 
 // ------------------------------------------------------------------------------------------
 // per-symbol backward
 // ------------------------------------------------------------------------------------------
-template <int CB>
+// EX: exactly CB levels per stream and two streams, both known at compile time (no bounds checks, levels in registers)
+template <int CB, bool EX = false>
 __device__ __forceinline__ void d_sym_bwd(const GridCtx gc, Lay l, const float* __restrict__ xhat, const float* __restrict__ levels,
                                                 const float* __restrict__ prior, const float* __restrict__ scaling,
                                                 const float* __restrict__ noise_var, const double* __restrict__ scal,
                                                 const float* __restrict__ grad_scale, float* __restrict__ ws,
                                                 float* __restrict__ gxhat) {
     __shared__ float red[NT / 64][2 * MAX_C];
+    const int C = EX ? CB : l.C, NS = EX ? 2 : l.ns;
     const float nv = noise_var[0];
     const float lam = (float)scal[V2VAE_SCAL_LAMBDA];
     const float gsc = grad_scale ? grad_scale[0] : 1.f;
@@ -658,20 +667,21 @@ __device__ __forceinline__ void d_sym_bwd(const GridCtx gc, Lay l, const float* 
 #pragma unroll
         for (int k = 0; k < CB; ++k) gs[c][k] = 0.f;
     double inv_den[2][MAX_C];
-    posterior_temperatures<CB>(scaling, l.C, nv, inv_den[0]);
-    posterior_temperatures<CB>(scaling + (l.ns - 1) * l.C, l.C, nv, inv_den[1]);
+    posterior_temperatures<CB>(scaling, C, nv, inv_den[0]);
+    posterior_temperatures<CB>(scaling + (NS - 1) * C, C, nv, inv_den[1]);
     // per-level constants, once per thread: 1 / prior, 1e-12 * prior, 1 / (nv sc) and 1 / (nv sc^2) in float
-    float inv_pr[2][MAX_C], eps_pr[2][MAX_C], idn_f[2][MAX_C], idn_sc[2][MAX_C];
+    float inv_pr[2][MAX_C], eps_pr[2][MAX_C], idn_f[2][MAX_C], idn_sc[2][MAX_C], lvr[2][MAX_C];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int k = 0; k < CB; ++k) {
-            const bool in = c < l.ns && k < l.C;
-            const float pr = in ? prior[c * l.C + k] : 1.f;
+            const bool in = c < NS && k < C;
+            const float pr = in ? prior[c * C + k] : 1.f;
+            lvr[c][k] = in ? levels[c * C + k] : 0.f;
             inv_pr[c][k] = 1.f / pr;
             eps_pr[c][k] = 1e-12f * pr;
             idn_f[c][k] = (float)inv_den[c][k];
-            idn_sc[c][k] = in ? idn_f[c][k] / scaling[c * l.C + k] : 0.f;
+            idn_sc[c][k] = in ? idn_f[c][k] / scaling[c * C + k] : 0.f;
         }
     // the loads of the next symbol are issued before the arithmetic of this one (the arithmetic is long enough to cover them)
     float nx[2], ng[2][4];
@@ -683,7 +693,7 @@ __device__ __forceinline__ void d_sym_bwd(const GridCtx gc, Lay l, const float* 
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             nx[c] = 0.f; ng[c][0] = 0.f; ng[c][1] = 0.f; ng[c][2] = 0.f; ng[c][3] = 0.f;
-            if (own && c < l.ns) {
+            if (own && c < NS) {
                 nx[c] = xhat[(int64_t)c * l.sym_cnt + i];
                 const float* g = gmom + (int64_t)c * 4 * l.sym_cnt + i;
                 if (l.cx_split) continue;
@@ -715,13 +725,13 @@ __device__ __forceinline__ void d_sym_bwd(const GridCtx gc, Lay l, const float* 
         fetch(i + stride);
 #pragma unroll
         for (int c = 0; c < 2; ++c)
-            if (c < l.ns) {
+            if (c < NS) {
                 float gx = 0.f;
                 if (own) {
                     const double x = xhat_full(l, ws, i, cx[c]);
-                    const float* lv = levels + c * l.C;
+                    const float* lv = lvr[c];
                     Posterior p;
-                    posterior<CB>(x, lv, inv_den[c], l.C, p);
+                    posterior<CB, EX>(x, lv, inv_den[c], C, p);
                     const float gmu = cg[c][0], gv = cg[c][1], gk = cg[c][2], gg = cg[c][3];
                     // Softmax backward in the pairwise form dz_k = q_k sum_j q_j (v_k - v_j): each term is a product of a
                     // (possibly tiny) probability with an O(1) difference, so nothing cancels against the posterior mean
@@ -729,7 +739,7 @@ __device__ __forceinline__ void d_sym_bwd(const GridCtx gc, Lay l, const float* 
                     float v[MAX_C];
 #pragma unroll
                     for (int k = 0; k < CB; ++k)
-                        if (k < l.C) {
+                        if (k < C) {
                             const float d = lv[k] - p.mu, d2 = d * d;
                             float vk = gmu * d + gv * d2 + gk * (d2 * d - 3.f * p.var * d) +
                                        gg * (d2 * d2 - 4.f * p.kap * d - 6.f * p.var * d2);
@@ -742,11 +752,11 @@ __device__ __forceinline__ void d_sym_bwd(const GridCtx gc, Lay l, const float* 
                     float gxa = 0.f;
 #pragma unroll
                     for (int k = 0; k < CB; ++k)
-                        if (k < l.C) {
+                        if (k < C) {
                             float sk = 0.f;
 #pragma unroll
                             for (int j = 0; j < CB; ++j)
-                                if (j < l.C && j != k) sk = fmaf(p.q[j], v[k] - v[j], sk);
+                                if (j < C && j != k) sk = fmaf(p.q[j], v[k] - v[j], sk);
                             const float dz = p.q[k] * sk;
                             const float df = (float)(x - (double)lv[k]);
                             gxa = fmaf(dz, -2.f * df * idn_f[c][k], gxa);
@@ -768,21 +778,21 @@ __device__ __forceinline__ void d_sym_bwd(const GridCtx gc, Lay l, const float* 
             if (lane == 0) red[wv][c * MAX_C + k] = v;
         }
     __syncthreads();
-    if (threadIdx.x < l.ns * l.C) {
-        const int c = threadIdx.x / l.C, k = threadIdx.x - c * l.C;
+    if (threadIdx.x < NS * C) {
+        const int c = threadIdx.x / C, k = threadIdx.x - c * C;
         float s = 0.f;
         for (int w = 0; w < NT / 64; ++w) s += red[w][c * MAX_C + k];
         ws[l.o_part_sym + (int64_t)gc.bid * l.rec_sym + threadIdx.x] = s;
     }
 }
 
-template <int CB>
+template <int CB, bool EX>
 __global__ __launch_bounds__(NT, CB <= 2 ? 4 : CB <= 4 ? 3 : CB <= 8 ? 2 : 1) void k_sym_bwd(Lay l, const float* __restrict__ xhat, const float* __restrict__ levels,
                                                 const float* __restrict__ prior, const float* __restrict__ scaling,
                                                 const float* __restrict__ noise_var, const double* __restrict__ scal,
                                                 const float* __restrict__ grad_scale, float* __restrict__ ws,
                                                 float* __restrict__ gxhat) {
-    d_sym_bwd<CB>(GridCtx{(int)blockIdx.x, (int)gridDim.x}, l, xhat, levels, prior, scaling, noise_var, scal, grad_scale, ws, gxhat);
+    d_sym_bwd<CB, EX>(GridCtx{(int)blockIdx.x, (int)gridDim.x}, l, xhat, levels, prior, scaling, noise_var, scal, grad_scale, ws, gxhat);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1756,14 +1766,20 @@ int v2vae_demap_moments(const v2vae_problem* p, const float* xhat, const float* 
     int rc = make_layout(p, &l);
     if (rc) return rc;
     if (!xhat || !levels || !prior || !scaling || !noise_var || !ws) return V2VAE_EINVAL;
-#define V2VAE_LAUNCH_DEMAP(CB)                                                                                     \
-    hipLaunchKernelGGL(k_demap_moments<CB>, dim3(l.nblk_dm),  dim3(NT), 0, (hipStream_t)stream, l, xhat, levels, prior, \
+#define V2VAE_LAUNCH_DEMAP_X(CB, EX)                                                                                    \
+    hipLaunchKernelGGL((k_demap_moments<CB, EX>), dim3(l.nblk_dm),  dim3(NT), 0, (hipStream_t)stream, l, xhat, levels, prior, \
                        scaling, noise_var, (float*)ws, q_out)
+#define V2VAE_LAUNCH_DEMAP(CB)                                                     \
+    do {                                                                           \
+        if (l.C == CB && l.ns == 2) V2VAE_LAUNCH_DEMAP_X(CB, true);                \
+        else V2VAE_LAUNCH_DEMAP_X(CB, false);                                      \
+    } while (0)
     if (l.C <= 2) V2VAE_LAUNCH_DEMAP(2);
     else if (l.C <= 4) V2VAE_LAUNCH_DEMAP(4);
     else if (l.C <= 8) V2VAE_LAUNCH_DEMAP(8);
     else V2VAE_LAUNCH_DEMAP(16);
 #undef V2VAE_LAUNCH_DEMAP
+#undef V2VAE_LAUNCH_DEMAP_X
     return launch_status();
 }
 
@@ -1839,14 +1855,20 @@ int v2vae_sym_bwd(const v2vae_problem* p, const float* xhat, const float* levels
     int rc = make_layout(p, &l);
     if (rc) return rc;
     if (!xhat || !levels || !prior || !scaling || !noise_var || !scal || !ws || !gxhat) return V2VAE_EINVAL;
-#define V2VAE_LAUNCH_SYMB(CB)                                                                                     \
-    hipLaunchKernelGGL(k_sym_bwd<CB>, dim3(l.nblk_sym), dim3(NT), 0, (hipStream_t)stream, l, xhat, levels, prior,     \
+#define V2VAE_LAUNCH_SYMB_X(CB, EX)                                                                                \
+    hipLaunchKernelGGL((k_sym_bwd<CB, EX>), dim3(l.nblk_sym), dim3(NT), 0, (hipStream_t)stream, l, xhat, levels, prior,   \
                        scaling, noise_var, scal, grad_scale, (float*)ws, gxhat)
+#define V2VAE_LAUNCH_SYMB(CB)                                                      \
+    do {                                                                           \
+        if (l.C == CB && l.ns == 2) V2VAE_LAUNCH_SYMB_X(CB, true);                 \
+        else V2VAE_LAUNCH_SYMB_X(CB, false);                                       \
+    } while (0)
     if (l.C <= 2) V2VAE_LAUNCH_SYMB(2);
     else if (l.C <= 4) V2VAE_LAUNCH_SYMB(4);
     else if (l.C <= 8) V2VAE_LAUNCH_SYMB(8);
     else V2VAE_LAUNCH_SYMB(16);
 #undef V2VAE_LAUNCH_SYMB
+#undef V2VAE_LAUNCH_SYMB_X
     return launch_status();
 }
 

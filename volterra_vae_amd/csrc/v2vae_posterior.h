@@ -22,9 +22,11 @@ __device__ __forceinline__ void posterior_temperatures(const float* __restrict__
     for (int i = 0; i < CB; ++i) inv_den[i] = i < C ? 1.0 / ((double)nv * (double)sc[i]) : 0.0;
 }
 
-template <int CB>
-__device__ __forceinline__ void posterior(double x, const float* __restrict__ lv, const double (&inv_den)[MAX_C], int C,
+// EX: the level count equals CB (known at compile time): no per-level bounds checks
+template <int CB, bool EX = false>
+__device__ __forceinline__ void posterior(double x, const float* __restrict__ lv, const double (&inv_den)[MAX_C], int C_rt,
                                           Posterior& p) {
+    const int C = EX ? CB : C_rt;
     // Logits reach |z| ~ 1e2..1e3 for small noise variance; rounding them to fp32 before the max is
     // subtracted would put ~|z| * 6e-8 of absolute error into the exponent, i.e. that much RELATIVE
     // error into q.  The difference z - max is therefore formed in double and only then rounded.
