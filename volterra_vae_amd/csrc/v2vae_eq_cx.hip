@@ -19,17 +19,23 @@ namespace v2vae {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// Sample tile [ns][tile_len] from global sample g0 on.  A tile that lies inside both the global sequence and the local
+// sample block (all but the first and last few) is copied without per-element checks; indices stay 32-bit inside the tile.
 __device__ __forceinline__ void eqcx_load_tile(const Lay& l, const float* __restrict__ y, int64_t g0, float* tile) {
-    const int n = l.ns * l.tile_len;
-    for (int idx = threadIdx.x; idx < n; idx += NT) {
-        const int c = idx / l.tile_len, i = idx - c * l.tile_len;
-        const int64_t g = g0 + i;
-        float v = 0.f;
-        if (g >= 0 && g < l.n_glob) {
-            const int64_t loc = g - l.y_lo;
-            if (loc >= 0 && loc < l.y_len) v = y[(int64_t)c * l.y_stride + loc];
+    const int tl = l.tile_len;
+    const int64_t loc0 = g0 - l.y_lo;
+    const bool inside = g0 >= 0 && g0 + tl <= l.n_glob && loc0 >= 0 && loc0 + tl <= l.y_len;   // uniform
+    for (int c = 0; c < l.ns; ++c) {
+        const float* __restrict__ src = y + (int64_t)c * l.y_stride + loc0;
+        float* dst = tile + c * tl;
+        if (inside) {
+            for (int i = threadIdx.x; i < tl; i += NT) dst[i] = src[i];
+        } else {
+            for (int i = threadIdx.x; i < tl; i += NT) {
+                const int64_t g = g0 + i, loc = loc0 + i;
+                dst[i] = (g >= 0 && g < l.n_glob && loc >= 0 && loc < l.y_len) ? src[i] : 0.f;
+            }
         }
-        tile[idx] = v;
     }
 }
 

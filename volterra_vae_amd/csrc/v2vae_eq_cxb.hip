@@ -367,18 +367,20 @@ __global__ __launch_bounds__(NT, T <= 25 ? 4 : T <= 31 ? 3 : 2) void k_eq_fwd_sy
         asm volatile("" : "+s"(tab_generic));
         const ctab_p tab = (ctab_p)tab_generic;
         __syncthreads();
-        {
-            const int64_t g0 = b0 * l.S - l.hl;
-            const int n = l.ns * tlen;
-            for (int idx = tid; idx < n; idx += NT) {
-                const int c = idx >= tlen ? 1 : 0, i = idx - c * tlen;
-                const int64_t g = g0 + i;
-                float v = 0.f;
-                if (g >= 0 && g < l.n_glob) {
-                    const int64_t loc = g - l.y_lo;
-                    if (loc >= 0 && loc < l.y_len) v = y[(int64_t)c * l.y_stride + loc];
+        {   // a tile inside the sequence and the local sample block (all but the ends) is copied without per-element checks
+            const int64_t g0 = b0 * l.S - l.hl, loc0 = g0 - l.y_lo;
+            const bool inside = g0 >= 0 && g0 + tlen <= l.n_glob && loc0 >= 0 && loc0 + tlen <= l.y_len;   // uniform
+            for (int c = 0; c < l.ns; ++c) {
+                const float* __restrict__ src = y + (int64_t)c * l.y_stride + loc0;
+                float* dst = tile + c * tlen;
+                if (inside) {
+                    for (int i = tid; i < tlen; i += NT) dst[i] = src[i];
+                } else {
+                    for (int i = tid; i < tlen; i += NT) {
+                        const int64_t g = g0 + i, loc = loc0 + i;
+                        dst[i] = (g >= 0 && g < l.n_glob && loc >= 0 && loc < l.y_len) ? src[i] : 0.f;
+                    }
                 }
-                tile[idx] = v;
             }
         }
         __syncthreads();
