@@ -106,16 +106,15 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
     constexpr int TWB = CXB_TWB, NU = CXB_NU, TP = XT ? CXB_TPX : CX_TP, NW = CXB_NW;
     constexpr int LEB = 16 * (NB + XT), EX = 16 * NB, MS = TWB + LEB + 16, NSIG = 32 + LEB, NWP = NW / S;
     constexpr int REC = 2 * LEB * LEB + 4 * LEB;
-    constexpr int STG = 11 * MS + 2 * S * TWB;
-    float* s_stage = sm;                       // moments float4 [2][MS] | means [2][MS] | s [MS] | y' [2][S][TWB]
+    constexpr int STG = 7 * MS + 2 * S * TWB;
+    // seven planes [MS] of per-symbol quantities, as the pair arithmetic reads them (two neighbouring taps per register pair):
+    // mean_a, mean_b, v_a + v_b, v_a - v_b, 3rd moment a, 3rd moment b, 4th cumulant a + b; then y' [2][S][TWB]
+    float* s_stage = sm;
     float* s_c = s_stage + STG;                // [S][4][LEB]  h1r, h1i, diag Hr, diag Hi
     float* s_T = s_c + S * 4 * LEB;            // [NW][32 * TP]  transposing buffer of rho / sigma
     float* s_P = s_T + NW * 32 * TP;           // [S][NU][4][NSIG] anti-diagonal partial sums
     float* s_rec = s_P + S * NU * 4 * NSIG;    // [S][REC]
-    // per-wave parking area for two of the six per-(window, tap) arrays that live from pass A to pass B (|z|^2 + 4 T and
-    // v_a - v_b): 48 registers per lane that would otherwise spill to scratch memory; [NW][2][NB * 8][64 lanes]
-    float* s_park = s_rec + S * REC;
-    float* s_xe = s_park + NW * 2 * NB * 8 * 64;   // XT: [S][2][LEB] row e of the symmetrised kernel (Re, Im)
+    float* s_xe = s_rec + S * REC;             // XT: [S][2][LEB] row e of the symmetrised kernel (Re, Im)
     __shared__ double dred[NW];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -124,8 +123,6 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
     // base per wave instead of one 64-bit address per lane and load)
     const int r = __builtin_amdgcn_readfirstlane(wv / NWP), wsub = __builtin_amdgcn_readfirstlane(wv % NWP);
     float* Tb = s_T + wv * 32 * TP;
-    float* park_zz = s_park + (size_t)wv * 2 * NB * 8 * 64 + lane;
-    float* park_dv = park_zz + NB * 8 * 64;
     const float* __restrict__ mom = ws + l.o_mom;
     float* __restrict__ gmom = ws + l.o_gmom;
     const int64_t own_hi = l.own_lo + l.own_cnt, sym_hi = l.sym_lo + l.sym_cnt;
@@ -144,7 +141,7 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
     const float* cst = s_c + r * 4 * LEB;
     __syncthreads();
     f32x4 Gr[NB][NB], Gi[NB][NB];
-    float ghr[NB][8], ghi[NB][8], gdr[NB][8], gdi[NB][8];
+    f2 ghr[NB][4], ghi[NB][4], gdr[NB][4], gdi[NB][4];   // vector gradients of the tap pairs (2 p, 2 p + 1) of each block
 #pragma unroll
     for (int a = 0; a < NB; ++a) {
 #pragma unroll
@@ -152,14 +149,14 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
 #pragma unroll
             for (int g = 0; g < 4; ++g) { Gr[a][b][g] = 0.f; Gi[a][b][g] = 0.f; }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { ghr[a][q] = 0.f; ghi[a][q] = 0.f; gdr[a][q] = 0.f; gdi[a][q] = 0.f; }
+        for (int q = 0; q < 4; ++q) { ghr[a][q] = 0.f; ghi[a][q] = 0.f; gdr[a][q] = 0.f; gdi[a][q] = 0.f; }
     }
     // extra tap e (XT): vector gradients, the (e, e) element, and row / column e of dE/dH in the transposed layout
     // (lane = (tap lane & 15, window group lane >> 4))
     float ghr_e = 0.f, ghi_e = 0.f, gdr_e = 0.f, gdi_e = 0.f, gee_r = 0.f, gee_i = 0.f;
-    float colr[NB], coli[NB], rowr[NB], rowi[NB];
+    f2 col[NB], row[NB];   // (Re, Im) of this lane's share of column e / row e of dE/dH
 #pragma unroll
-    for (int a = 0; a < NB; ++a) { colr[a] = 0.f; coli[a] = 0.f; rowr[a] = 0.f; rowi[a] = 0.f; }
+    for (int a = 0; a < NB; ++a) { col[a] = 0.f; row[a] = 0.f; }
     const float* __restrict__ Xbase0 = ws + l.o_cxbA + (size_t)S * NB * NB * 40 * 64 + (size_t)r * NB * 2 * 64;
     double Eacc = 0.0;
 #ifdef V2VAE_STAMPS
@@ -214,22 +211,23 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
         }
     };
     auto stage_store = [&](float* dst) {
-        float4* d4 = reinterpret_cast<float4*>(dst);
 #pragma unroll
         for (int u = 0; u < NSL; ++u) {
             const int ms = tid + u * CXB_NT;
             if (ms < MS) {
-                d4[ms] = prea[u];
-                d4[MS + ms] = preb[u];
-                dst[8 * MS + ms] = prea[u].x;
-                dst[9 * MS + ms] = preb[u].x;
-                dst[10 * MS + ms] = prea[u].y + preb[u].y;
+                dst[ms] = prea[u].x;
+                dst[MS + ms] = preb[u].x;
+                dst[2 * MS + ms] = prea[u].y + preb[u].y;
+                dst[3 * MS + ms] = prea[u].y - preb[u].y;
+                dst[4 * MS + ms] = prea[u].z;
+                dst[5 * MS + ms] = preb[u].z;
+                dst[6 * MS + ms] = prea[u].w + preb[u].w;
             }
         }
 #pragma unroll
         for (int u = 0; u < NYW; ++u) {
             const int e = tid + u * CXB_NT;
-            if (e < 2 * S * TWB) dst[11 * MS + e] = prey[u];
+            if (e < 2 * S * TWB) dst[7 * MS + e] = prey[u];
         }
     };
     if ((int)blockIdx.x < l.ntile_cxb) { stage_load(blockIdx.x); stage_store(s_stage); }
@@ -239,10 +237,13 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
         const int64_t s0 = l.own_lo + (int64_t)tile * TS;
         const int64_t s1 = (s0 + TS < own_hi) ? s0 + TS : own_hi;
         const int64_t tbase = s0 - l.kmax;
-        const float4* s_m4 = reinterpret_cast<const float4*>(s_stage);   // [2][MS]
-        const float* s_mu = s_stage + 8 * MS;                             // [2][MS]
-        const float* s_S = s_mu + 2 * MS;
-        const float* s_yw = s_S + MS;
+        const float* s_mu = s_stage;            // [2][MS]
+        const float* s_S = s_stage + 2 * MS;
+        const float* s_dv = s_stage + 3 * MS;
+        const float* s_ka = s_stage + 4 * MS;
+        const float* s_kb = s_stage + 5 * MS;
+        const float* s_gs = s_stage + 6 * MS;
+        const float* s_yw = s_stage + 7 * MS;
         const bool more = tile + (int)gridDim.x < l.ntile_cxb;
 
         BSTAMP(0);
@@ -265,8 +266,8 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
             const gfloat_p Abase = (gfloat_p)Abase_generic;
 
             // ---- pass A: per output block H X and (H.H) s, then the per-(window, tap) algebra that does not need e
-            float zP[NB][8], zQ[NB][8], al[NB][8], be[NB][8];
-            float a0 = 0.f, a1 = 0.f, q0 = 0.f, q1 = 0.f, sd0 = 0.f, sd1 = 0.f, vs = 0.f;
+            f2 zP[NB][4], zQ[NB][4], al[NB][4], be[NB][4];   // tap pairs (2 p, 2 p + 1): neighbouring accumulator registers, taps x, x + 1
+            f2 a0v = 0.f, a1v = 0.f, q0v = 0.f, q1v = 0.f, sd0v = 0.f, sd1v = 0.f, vsv = 0.f;
             // the A operands of block pair p + 1 are requested before the MFMA chain of pair p is issued; sched_barrier keeps
             // the compiler from hoisting more than that one pair of loads (register budget)
             float abuf[2][16];   // two register sets, alternating by block pair: no copies
@@ -308,35 +309,33 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                 if (XT) U = MFMA32(xbufA[xb], s_mu[h * MS + tsl + i + EX], U);
                 BSTAMP(1);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int x = 16 * xb + cx_kk(q, h);
+                for (int p = 0; p < 4; ++p) {
+                    const int x = 16 * xb + cx_kk(2 * p, h);
                     const int slot = tsl + i + x;
-                    const float P = U[q], Q = U[q + 8];
-                    const float4 m4a = s_m4[slot], m4b = s_m4[MS + slot];
-                    const float ma = m4a.x, va = m4a.y, ka = m4a.z, ga = m4a.w;
-                    const float mb = m4b.x, vb = m4b.y, kb = m4b.z, gb = m4b.w;
-                    const float hr = cst[x], hi = cst[LEB + x], dr = cst[2 * LEB + x], di = cst[3 * LEB + x];
-                    const float zp = fmaf(2.f, P, hr), zq = fmaf(2.f, Q, hi);
-                    a0 += hr * ma - hi * mb;
-                    a1 += hi * ma + hr * mb;
-                    q0 += ma * P - mb * Q;
-                    q1 += ma * Q + mb * P;
-                    const float Sv = va + vb, dv = va - vb, gs = ga + gb;
-                    sd0 = fmaf(dv, dr, sd0);
-                    sd1 = fmaf(dv, di, sd1);
-                    const float z2 = zp * zp + zq * zq;
-                    const float ca = dr * zp + di * zq, cb = dr * zq - di * zp;
-                    vs += Sv * z2 + 2.f * (ka * ca + kb * cb) + gs * (dr * dr + di * di);
-                    al[xb][q] = 2.f * Sv * zp + 2.f * (ka * dr - kb * di);
-                    be[xb][q] = 2.f * Sv * zq + 2.f * (ka * di + kb * dr);
-                    zP[xb][q] = zp; zQ[xb][q] = zq;
-                    park_zz[(xb * 8 + q) * 64] = z2;
-                    park_dv[(xb * 8 + q) * 64] = dv;
-                    gdr[xb][q] += mo * (2.f * (ka * zp + kb * zq) + 2.f * gs * dr);
-                    gdi[xb][q] += mo * (2.f * (ka * zq - kb * zp) + 2.f * gs * di);
+                    const f2 P = f2{U[2 * p], U[2 * p + 1]}, Q = f2{U[2 * p + 8], U[2 * p + 9]};
+                    const f2 ma = ld2(s_mu + slot), mb = ld2(s_mu + MS + slot), Sv = ld2(s_S + slot), dv = ld2(s_dv + slot);
+                    const f2 ka = ld2(s_ka + slot), kb = ld2(s_kb + slot), gs = ld2(s_gs + slot);
+                    const f2 hr = ld2(cst + x), hi = ld2(cst + LEB + x), dr = ld2(cst + 2 * LEB + x), di = ld2(cst + 3 * LEB + x);
+                    const f2 zp = 2.f * P + hr, zq = 2.f * Q + hi;
+                    a0v += hr * ma - hi * mb;
+                    a1v += hi * ma + hr * mb;
+                    q0v += ma * P - mb * Q;
+                    q1v += ma * Q + mb * P;
+                    sd0v += dv * dr;
+                    sd1v += dv * di;
+                    const f2 z2 = zp * zp + zq * zq;
+                    const f2 ca = dr * zp + di * zq, cb = dr * zq - di * zp;
+                    vsv += Sv * z2 + 2.f * (ka * ca + kb * cb) + gs * (dr * dr + di * di);
+                    al[xb][p] = 2.f * (Sv * zp + ka * dr - kb * di);
+                    be[xb][p] = 2.f * (Sv * zq + ka * di + kb * dr);
+                    zP[xb][p] = zp; zQ[xb][p] = zq;
+                    gdr[xb][p] += (2.f * mo) * (ka * zp + kb * zq + gs * dr);
+                    gdi[xb][p] += (2.f * mo) * (ka * zq - kb * zp + gs * di);
                 }
                 BSTAMP(2);
             }
+            float a0 = a0v.x + a0v.y, a1 = a1v.x + a1v.y, q0 = q0v.x + q0v.y, q1 = q1v.x + q1v.y;
+            float sd0 = sd0v.x + sd0v.y, sd1 = sd1v.x + sd1v.y, vs = vsv.x + vsv.y;
             a0 += __shfl_xor(a0, 32); a1 += __shfl_xor(a1, 32);
             q0 += __shfl_xor(q0, 32); q1 += __shfl_xor(q1, 32);
             sd0 += __shfl_xor(sd0, 32); sd1 += __shfl_xor(sd1, 32);
@@ -345,22 +344,22 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
             // halves are added), then the same per-(window, tap) algebra; both halves hold identical values from here on
             float zp_e = 0.f, zq_e = 0.f, al_e = 0.f, be_e = 0.f, z2_e = 0.f, dv_e = 0.f, ma_e = 0.f, mb_e = 0.f;
             if (XT) {
-                float pe = 0.f, qe = 0.f;
+                f2 pe2 = 0.f, qe2 = 0.f;
 #pragma unroll
                 for (int jb = 0; jb < NB; ++jb)
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int j = 16 * jb + cx_kk(q, h);
-                        const float ma = s_mu[tsl + i + j], mb = s_mu[MS + tsl + i + j];
-                        const float cr = xe[j], ci = xe[LEB + j];
-                        pe += ma * cr - mb * ci;
-                        qe += ma * ci + mb * cr;
+                    for (int p = 0; p < 4; ++p) {
+                        const int j = 16 * jb + cx_kk(2 * p, h);
+                        const f2 ma = ld2(s_mu + tsl + i + j), mb = ld2(s_mu + MS + tsl + i + j);
+                        const f2 cr = ld2(xe + j), ci = ld2(xe + LEB + j);
+                        pe2 += ma * cr - mb * ci;
+                        qe2 += ma * ci + mb * cr;
                     }
+                float pe = pe2.x + pe2.y, qe = qe2.x + qe2.y;
                 pe += __shfl_xor(pe, 32); qe += __shfl_xor(qe, 32);
                 const int slot = tsl + i + EX;
-                const float4 m4a = s_m4[slot], m4b = s_m4[MS + slot];
-                const float ma = m4a.x, va = m4a.y, ka = m4a.z, ga = m4a.w;
-                const float mb = m4b.x, vb = m4b.y, kb = m4b.z, gb = m4b.w;
+                const float ma = s_mu[slot], mb = s_mu[MS + slot], Sv = s_S[slot], dv = s_dv[slot];
+                const float ka = s_ka[slot], kb = s_kb[slot], gs = s_gs[slot];
                 pe += ma * xe[EX] - mb * xe[LEB + EX];
                 qe += ma * xe[LEB + EX] + mb * xe[EX];
                 const float hr = cst[EX], hi = cst[LEB + EX], dr = cst[2 * LEB + EX], di = cst[3 * LEB + EX];
@@ -369,7 +368,6 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                 a1 += hi * ma + hr * mb;
                 q0 += ma * pe - mb * qe;
                 q1 += ma * qe + mb * pe;
-                const float Sv = va + vb, dv = va - vb, gs = ga + gb;
                 sd0 = fmaf(dv, dr, sd0);
                 sd1 = fmaf(dv, di, sd1);
                 const float z2 = zp * zp + zq * zq;
@@ -389,16 +387,17 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
             // ---- extra tap e, second half: its row of H w from the registers, its anti-diagonal terms (window i -> symbol slot
             // i + e, no reduction needed), vector gradients, and rho / sigma of tap e for row e of dE/dH
             if (XT) {
-                float hwa = 0.f, hwb = 0.f;
+                f2 hwa2 = 0.f, hwb2 = 0.f;
 #pragma unroll
                 for (int jb = 0; jb < NB; ++jb)
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int j = 16 * jb + cx_kk(q, h);
-                        const float cr = xe[j], ci = xe[LEB + j];
-                        hwa += al[jb][q] * cr + be[jb][q] * ci;
-                        hwb += be[jb][q] * cr - al[jb][q] * ci;
+                    for (int p = 0; p < 4; ++p) {
+                        const int j = 16 * jb + cx_kk(2 * p, h);
+                        const f2 cr = ld2(xe + j), ci = ld2(xe + LEB + j);
+                        hwa2 += al[jb][p] * cr + be[jb][p] * ci;
+                        hwb2 += be[jb][p] * cr - al[jb][p] * ci;
                     }
+                float hwa = hwa2.x + hwa2.y, hwb = hwb2.x + hwb2.y;
                 hwa += __shfl_xor(hwa, 32); hwb += __shfl_xor(hwb, 32);
                 hwa += al_e * xe[EX] + be_e * xe[LEB + EX];
                 hwb += be_e * xe[EX] - al_e * xe[LEB + EX];
@@ -442,7 +441,8 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int s = 0; s < 16; ++s) HW = MFMA32(hbuf[pr & 1][s], s < 8 ? al[jb][s & 7] : be[jb][s & 7], HW);
+                    for (int s = 0; s < 16; ++s)
+                        HW = MFMA32(hbuf[pr & 1][s], s < 8 ? al[jb][(s & 7) >> 1][s & 1] : be[jb][(s & 7) >> 1][s & 1], HW);
                 }
                 if (XT) HW = MFMA32(xbufB[xb], h == 0 ? al_e : be_e, HW);
                 BSTAMP(3);
@@ -453,20 +453,21 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                 for (int round = 0; round < 2; ++round) {
                     float da[8], db[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int x = 16 * xb + cx_kk(q, h);
-                        const float zp = zP[xb][q], zq = zQ[xb][q], dr = cst[2 * LEB + x], di = cst[3 * LEB + x];
+                    for (int p = 0; p < 4; ++p) {
+                        const int x = 16 * xb + cx_kk(2 * p, h);
+                        const f2 zp = zP[xb][p], zq = zQ[xb][p];
+                        f2 d0, d1;
                         if (round == 0) {
-                            da[q] = 2.f * (e0 * zp + e1 * zq) + 2.f * HW[q];
-                            db[q] = 2.f * (e1 * zp - e0 * zq) + 2.f * HW[q + 8];
+                            d0 = (2.f * mv) * (e0 * zp + e1 * zq + f2{HW[2 * p], HW[2 * p + 1]});
+                            d1 = (2.f * mv) * (e1 * zp - e0 * zq + f2{HW[2 * p + 8], HW[2 * p + 9]});
                         } else {
-                            const float ed = 2.f * (e0 * dr + e1 * di);
-                            const float zzq = park_zz[(xb * 8 + q) * 64];
-                            da[q] = zzq + ed;
-                            db[q] = zzq - ed;
+                            const f2 dr = ld2(cst + 2 * LEB + x), di = ld2(cst + 3 * LEB + x);
+                            const f2 ed = 2.f * (e0 * dr + e1 * di), zzp = zp * zp + zq * zq;
+                            d0 = mv * (zzp + ed);
+                            d1 = mv * (zzp - ed);
                         }
-                        da[q] *= mv;
-                        db[q] *= mv;
+                        da[2 * p] = d0.x; da[2 * p + 1] = d0.y;
+                        db[2 * p] = d1.x; db[2 * p + 1] = d1.y;
                     }
                     const float sa = cx_antidiag(da), sb = cx_antidiag(db);
                     if (lane < 48) {
@@ -477,18 +478,20 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                 BSTAMP(4);
                 // rho / sigma of this block (transposed through LDS), vector gradients
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int xl = cx_kk(q, h);
+                for (int p = 0; p < 4; ++p) {
+                    const int xl = cx_kk(2 * p, h);
                     const int slot = tsl + i + 16 * xb + xl;
-                    const float ma = s_mu[slot], mb = s_mu[MS + slot];
-                    const float gr = 2.f * (e0 * ma + e1 * mb), gi = 2.f * (e1 * ma - e0 * mb);
-                    ghr[xb][q] += mo * (gr + al[xb][q]);
-                    ghi[xb][q] += mo * (gi + be[xb][q]);
-                    const float dvq = park_dv[(xb * 8 + q) * 64];
-                    gdr[xb][q] += mo * 2.f * e0 * dvq;
-                    gdi[xb][q] += mo * 2.f * e1 * dvq;
-                    Tb[i * TP + xl] = mo * (gr + 2.f * al[xb][q]);
-                    Tb[i * TP + 16 + xl] = mo * (gi + 2.f * be[xb][q]);
+                    const f2 ma = ld2(s_mu + slot), mb = ld2(s_mu + MS + slot), dvq = ld2(s_dv + slot);
+                    const f2 gr = 2.f * (e0 * ma + e1 * mb), gi = 2.f * (e1 * ma - e0 * mb);
+                    ghr[xb][p] += mo * (gr + al[xb][p]);
+                    ghi[xb][p] += mo * (gi + be[xb][p]);
+                    gdr[xb][p] += (mo * 2.f * e0) * dvq;
+                    gdi[xb][p] += (mo * 2.f * e1) * dvq;
+                    const f2 t0 = mo * (gr + 2.f * al[xb][p]), t1 = mo * (gi + 2.f * be[xb][p]);
+                    Tb[i * TP + xl] = t0.x;
+                    Tb[i * TP + xl + 1] = t0.y;
+                    Tb[i * TP + 16 + xl] = t1.x;
+                    Tb[i * TP + 16 + xl + 1] = t1.y;
                 }
                 __builtin_amdgcn_wave_barrier();
                 {
@@ -503,9 +506,8 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
 #pragma unroll
                         for (int st = 0; st < 8; ++st) {
                             const int w = tsl + 4 * st + kq + EX;
-                            const float mae = s_mu[w], mbe = s_mu[MS + w];
-                            colr[xb] += ar[st] * mae + as[st] * mbe;
-                            coli[xb] += as[st] * mae - ar[st] * mbe;
+                            const f2 me = {s_mu[w], s_mu[MS + w]};
+                            col[xb] += ar[st] * f2{me.x, -me.y} + as[st] * f2{me.y, me.x};
                         }
                     }
 #pragma unroll
@@ -519,9 +521,8 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                             Gi[xb][jb] = MFMA16(as[st], ma, Gi[xb][jb]);
                             Gi[xb][jb] = MFMA16(-ar[st], mb, Gi[xb][jb]);
                             if (XT && xb == 0) {   // row e of dE/dH, once per slab: sum_w (rho, sigma)(w, e) mu(w + j)
-                                const float Re = Tb[(4 * st + kq) * TP + 32], Se = Tb[(4 * st + kq) * TP + 33];
-                                rowr[jb] += Re * ma + Se * mb;
-                                rowi[jb] += Se * ma - Re * mb;
+                                const f2 rs = ld2(Tb + (4 * st + kq) * TP + 32);   // (rho, sigma) of tap e at this window
+                                row[jb] += ma * rs + mb * f2{rs.y, -rs.x};
                             }
                         }
                     }
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                     }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    float v0 = ghr[xb][q], v1 = ghi[xb][q], v2 = gdr[xb][q], v3 = gdi[xb][q];
+                    float v0 = ghr[xb][q >> 1][q & 1], v1 = ghi[xb][q >> 1][q & 1], v2 = gdr[xb][q >> 1][q & 1], v3 = gdi[xb][q >> 1][q & 1];
 #pragma unroll
                     for (int off = 1; off < 32; off <<= 1) {
                         v0 += __shfl_xor(v0, off); v1 += __shfl_xor(v1, off);
@@ -599,7 +600,7 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
             if (XT) {
 #pragma unroll
                 for (int xb = 0; xb < NB; ++xb) {
-                    float c0 = colr[xb], c1 = coli[xb], r0 = rowr[xb], r1 = rowi[xb];
+                    float c0 = col[xb].x, c1 = col[xb].y, r0 = row[xb].x, r1 = row[xb].y;
                     c0 += __shfl_xor(c0, 16); c1 += __shfl_xor(c1, 16); r0 += __shfl_xor(r0, 16); r1 += __shfl_xor(r1, 16);
                     c0 += __shfl_xor(c0, 32); c1 += __shfl_xor(c1, 32); r0 += __shfl_xor(r0, 32); r1 += __shfl_xor(r1, 32);
                     if (lane < 16) {
