@@ -69,22 +69,25 @@ __global__ __launch_bounds__(NT) void k_prep_eqcxb(Lay l, const float* __restric
         const int jj = p1 + p2 - x;  // first-order tap that multiplies lag x
         ws[l.o_eqcxbA + n + idx] = (x < l2 && jj >= 0 && jj < l1) ? (plane == 0 ? k1r[jj] : k1i[jj]) : 0.f;
     }
-    if (l.eqsym_t) {   // table of the symmetric-form forward kernel (k_eq_fwd_sym)
-        const int T = l.eqsym_t, np = T * (T + 1) / 2;
-        for (int idx = blockIdx.x * NT + threadIdx.x; idx < np + T; idx += gridDim.x * NT) {
+    if (l.eqsym_t) {   // table of the symmetric-form forward kernel (k_eq_fwd_sym): one stream of (Re, Im) entries, row after row,
+                       // row a = [first-order weight of lag a, K'_aa, K'_a,a+1, ..., K'_a,T-1]; eight zero entries pad the end
+        const int T = l.eqsym_t, ne = T * (T + 1) / 2 + T;
+        for (int idx = blockIdx.x * NT + threadIdx.x; idx < ne + 8; idx += gridDim.x * NT) {
             float vr = 0.f, vi = 0.f;
-            if (idx < np) {
+            if (idx < ne) {
                 int a = 0, rem = idx;
-                while (rem >= T - a) { rem -= T - a; ++a; }
-                const int b = a + rem;
-                if (b < l2) {
-                    const float sc = a == b ? 1.f : 2.f;   // K_ab y_a y_b + K_ba y_b y_a
-                    vr = sc * (k2r[a * l2 + b] + k2r[b * l2 + a]);
-                    vi = sc * (k2i[a * l2 + b] + k2i[b * l2 + a]);
+                while (rem >= T - a + 1) { rem -= T - a + 1; ++a; }
+                if (rem == 0) {
+                    const int jj = p1 + p2 - a;  // first-order tap that multiplies lag a
+                    if (a < l2 && jj >= 0 && jj < l1) { vr = k1r[jj]; vi = k1i[jj]; }
+                } else {
+                    const int b = a + rem - 1;
+                    if (b < l2) {
+                        const float sc = a == b ? 1.f : 2.f;   // K_ab y_a y_b + K_ba y_b y_a
+                        vr = sc * (k2r[a * l2 + b] + k2r[b * l2 + a]);
+                        vi = sc * (k2i[a * l2 + b] + k2i[b * l2 + a]);
+                    }
                 }
-            } else {
-                const int x = idx - np, jj = p1 + p2 - x;  // first-order tap that multiplies lag x
-                if (x < l2 && jj >= 0 && jj < l1) { vr = k1r[jj]; vi = k1i[jj]; }
             }
             ws[l.o_eqsym + 2 * idx] = vr;
             ws[l.o_eqsym + 2 * idx + 1] = vi;
@@ -327,6 +330,7 @@ int launch_prep_eqcxb(const Lay& l, const float* k1, const float* k2, float* ws,
 // symbol per thread: its T samples sit in registers, the kernel entries are wave-uniform (scalar loads), every multiply-add is
 // two packed FMAs.
 typedef float eq_f2 __attribute__((ext_vector_type(2)));
+typedef unsigned long long eq_k8 __attribute__((ext_vector_type(8)));   // eight (Re, Im) table entries
 
 // Kernels of up to 31 lags take NSY = 2 symbols per thread (a tile of 512 symbols): every kernel entry fetched serves both, which
 // halves the scalar-load waits the instruction stream is bound by.
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(NT, T <= 25 ? 4 : T <= 31 ? 3 : 2) void k_eq_fwd_sy
     constexpr int NSY = T <= 31 ? 2 : 1, TB = NSY * EQ_TB;
     const int tid = threadIdx.x;
     const float* tab0 = ws + l.o_eqsym;
-    constexpr int NP = T * (T + 1) / 2;
+    constexpr int NE = T * (T + 1) / 2 + T;
     const int64_t sym_hi = l.sym_lo + l.sym_cnt;
     const int64_t ntile = (l.sym_cnt + TB - 1) / TB;
     const int tlen = l.tile_len + (NSY - 1) * EQ_TB * l.S;
@@ -394,23 +398,24 @@ __global__ __launch_bounds__(NT, T <= 25 ? 4 : T <= 31 ? 3 : 2) void k_eq_fwd_sy
                 yv[n][x] = in ? eq_f2{tile[base - x], tile[tlen + base - x]} : eq_f2{0.f, 0.f};
             }
         }
-        eq_f2 out[NSY];
+        eq_f2 out[NSY], u[NSY];
 #pragma unroll
-        for (int n = 0; n < NSY; ++n) out[n] = eq_f2{0.f, 0.f};
-        int p = 0;
+        for (int n = 0; n < NSY; ++n) { out[n] = eq_f2{0.f, 0.f}; u[n] = out[n]; }
+        // the table is one stream of entries, fetched eight at a time (one 64-byte scalar load, one wait per eight entries)
+        // wherever the flat index crosses a multiple of eight; all indices are compile-time constants after unrolling
+        eq_k8 kk;
 #pragma unroll
         for (int a = 0; a < T; ++a) {
-            eq_f2 u[NSY];
-            {
-                const unsigned long long k1w = tab[NP + a];
+            const int off = a * (T + 1) - a * (a - 1) / 2;   // flat index of the first-order weight that opens row a
+            if ((off & 7) == 0) kk = *reinterpret_cast<const eq_k8 __attribute__((address_space(4)))*>(tab + off);
 #pragma unroll
-                for (int n = 0; n < NSY; ++n) u[n] = __builtin_bit_cast(eq_f2, k1w);
-            }
+            for (int n = 0; n < NSY; ++n) u[n] = __builtin_bit_cast(eq_f2, (unsigned long long)kk[off & 7]);
 #pragma unroll
-            for (int b = a; b < T; ++b, ++p) {
-                const unsigned long long K = tab[p];
+            for (int b = a; b < T; ++b) {
+                const int idx = off + 1 + (b - a);
+                if ((idx & 7) == 0) kk = *reinterpret_cast<const eq_k8 __attribute__((address_space(4)))*>(tab + idx);
 #pragma unroll
-                for (int n = 0; n < NSY; ++n) eq_cmac_s(u[n], K, yv[n][b]);
+                for (int n = 0; n < NSY; ++n) eq_cmac_s(u[n], kk[idx & 7], yv[n][b]);
             }
 #pragma unroll
             for (int n = 0; n < NSY; ++n) eq_cmac_v(out[n], u[n], yv[n][a]);
