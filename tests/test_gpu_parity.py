@@ -259,10 +259,12 @@ def test_complex_long_equaliser_blocked_kernel_matches_oracle(l1, l2, S, B):
     assert rel(out["g"]["h1"], th1.grad) < TOL
 
 
-@pytest.mark.parametrize("L,S,B", [(25, 2, 5000), (25, 2, 331), (16, 1, 2049), (31, 2, 1500), (9, 2, 700)])
+@pytest.mark.parametrize("L,S,B", [(25, 2, 5000), (25, 2, 331), (16, 1, 2049), (31, 2, 1500), (9, 2, 700), (65, 2, 1300),
+                                   (33, 1, 700), (33, 2, 900)])
 def test_run_and_block_tile_elbo_kernels_agree(L, S, B):
     """The two matrix-core ELBO kernels of the complex model (every wave on its own run of windows - the default - and the
-    earlier block-tile kernel, V2VAE_FLAG_ELBO_TILES) are different programs for the same sums."""
+    earlier block-tile kernel, V2VAE_FLAG_ELBO_TILES) are different programs for the same sums; so are, at 17 and 33 active
+    taps per phase, the blocked kernel with one tap carried on the side (the default) and with whole blocks of 16 (the flag)."""
     from volterra_vae_amd import _lib
     from volterra_vae_amd.ops import Plan
     l1 = l2 = 25
