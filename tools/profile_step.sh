@@ -5,7 +5,8 @@ set -e
 OUT=$1
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-B="python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline"
+# BENCH_ARGS: extra arguments of bench.py, e.g. "--workload cfg4"
+B="python3 bench.py --steps ${STEPS:-30} --warmup 3 --no-cpu-baseline $BENCH_ARGS"
 timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o step -- $B > $OUT/bench_profiled.json 2> $OUT/stats.err
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $B > /dev/null 2> $OUT/fetch.err
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $B > /dev/null 2> $OUT/write.err

@@ -19,22 +19,24 @@ namespace v2vae {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-// Sample tile [ns][tile_len] from global sample g0 on.  A tile that lies inside both the global sequence and the local
-// sample block (all but the first and last few) is copied without per-element checks; indices stay 32-bit inside the tile.
+// Sample tile from global sample g0 on, the two streams INTERLEAVED ([tile_len][2]: one 8-byte LDS read gives both parts of
+// a sample).  A tile that lies inside both the global sequence and the local sample block (all but the first and last few) is
+// copied without per-element checks; indices stay 32-bit inside the tile.
 __device__ __forceinline__ void eqcx_load_tile(const Lay& l, const float* __restrict__ y, int64_t g0, float* tile) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
     const int tl = l.tile_len;
     const int64_t loc0 = g0 - l.y_lo;
     const bool inside = g0 >= 0 && g0 + tl <= l.n_glob && loc0 >= 0 && loc0 + tl <= l.y_len;   // uniform
-    for (int c = 0; c < l.ns; ++c) {
-        const float* __restrict__ src = y + (int64_t)c * l.y_stride + loc0;
-        float* dst = tile + c * tl;
-        if (inside) {
-            for (int i = threadIdx.x; i < tl; i += NT) dst[i] = src[i];
-        } else {
-            for (int i = threadIdx.x; i < tl; i += NT) {
-                const int64_t g = g0 + i, loc = loc0 + i;
-                dst[i] = (g >= 0 && g < l.n_glob && loc >= 0 && loc < l.y_len) ? src[i] : 0.f;
-            }
+    const float* __restrict__ sa = y + loc0;
+    const float* __restrict__ sb = y + l.y_stride + loc0;
+    f2* dst = reinterpret_cast<f2*>(tile);
+    if (inside) {
+        for (int i = threadIdx.x; i < tl; i += NT) dst[i] = f2{sa[i], sb[i]};
+    } else {
+        for (int i = threadIdx.x; i < tl; i += NT) {
+            const int64_t g = g0 + i, loc = loc0 + i;
+            const bool in = g >= 0 && g < l.n_glob && loc >= 0 && loc < l.y_len;
+            dst[i] = in ? f2{sa[i], sb[i]} : f2{0.f, 0.f};
         }
     }
 }
@@ -42,7 +44,7 @@ __device__ __forceinline__ void eqcx_load_tile(const Lay& l, const float* __rest
 // NB16 = blocks of 16 lag rows (lags 0 .. l2, the ones column at index l2 included): 2 for up to 31 lags, ... 5 for up to 79.
 // SS = samples per symbol when it is 1 or 2 (the sample offsets of the unrolled symbol loop are then instruction immediates),
 // 0 = read from the layout.
-// LDS: sample tile [ns][tile_len] | per-symbol gradient combinations, 4-vectors [EQ_TB] and a plane [EQ_TB] | ones [64 S] | zeros [64 S].
+// LDS: sample tile [tile_len][2] | per-symbol gradient combinations, 4-vectors [EQ_TB] and a plane [EQ_TB] | constant (1, 0) samples [64 S][2].
 template <int NB16, int SS>
 __global__ __launch_bounds__(NT, NB16 <= 3 ? 4 : 2) void k_eq_bwd_cx(Lay l, const float* __restrict__ y, const float* __restrict__ gx,
                                                                   float* __restrict__ ws) {
@@ -51,9 +53,9 @@ __global__ __launch_bounds__(NT, NB16 <= 3 ? 4 : 2) void k_eq_bwd_cx(Lay l, cons
     const int S = SS ? SS : l.S;
     float* tile = sm;
     const int ntl = (l.ns * l.tile_len + 3) & ~3;
-    f32x4* g4 = reinterpret_cast<f32x4*>(sm + ntl);   // (g0 + g1, g1 - g0, g1, -g0) per symbol of the tile
+    f32x4* g4 = reinterpret_cast<f32x4*>(sm + ntl);   // (g0 + g1, g1, g1 - g0, -g0) per symbol of the tile
     float* ng1 = sm + ntl + 4 * EQ_TB;                 // -g1
-    const int o_ones = ntl + 5 * EQ_TB, o_zeros = o_ones + 64 * S;
+    const int o_ones = ntl + 5 * EQ_TB;   // (1, 0) pairs
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int i16 = lane & 15, kq = lane >> 4;
     // Both gradient planes are symmetric in the lag pair, so only the upper-triangular 16x16 blocks (ib <= jb) are
@@ -70,18 +72,17 @@ __global__ __launch_bounds__(NT, NB16 <= 3 ? 4 : 2) void k_eq_bwd_cx(Lay l, cons
     for (int q = 0; q < NBLK; ++q)
 #pragma unroll
         for (int g = 0; g < 4; ++g) { A[q][g] = 0.f; B[q][g] = 0.f; C[q][g] = 0.f; }
-    for (int idx = tid; idx < 128 * S; idx += NT) sm[o_ones + idx] = idx < 64 * S ? 1.f : 0.f;
+    for (int idx = tid; idx < 128 * S; idx += NT) sm[o_ones + idx] = (idx & 1) ? 0.f : 1.f;
     // per-lane sample positions of symbol (wave base + kq) for each block; rows / columns from l2 on read the constants (their rows
     // are never read back, column l2 is the ones column)
-    const float* pa[NB16];
-    const float* pb[NB16];
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2* pa[NB16];
     {
         const int base0 = (wv * 64 + kq) * S + l.hl + l.p2;
 #pragma unroll
         for (int ib = 0; ib < NB16; ++ib) {
             const int j = 16 * ib + i16;
-            pa[ib] = sm + (j >= l.l2 ? o_ones : base0 - j);
-            pb[ib] = sm + (j >= l.l2 ? o_zeros : l.tile_len + base0 - j);
+            pa[ib] = reinterpret_cast<const f2*>(sm + (j >= l.l2 ? o_ones : 2 * (base0 - j)));
         }
     }
     for (int t = blockIdx.x; t < l.ntile_eq; t += gridDim.x) {
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(NT, NB16 <= 3 ? 4 : 2) void k_eq_bwd_cx(Lay l, cons
         {   // EQ_TB == NT: one symbol per thread
             const float g0 = tid < nbs ? gx[b0 + tid - l.sym_lo] : 0.f;
             const float g1 = tid < nbs ? gx[l.sym_cnt + (b0 + tid - l.sym_lo)] : 0.f;
-            g4[tid] = f32x4{g0 + g1, g1 - g0, g1, -g0};
+            g4[tid] = f32x4{g0 + g1, g1, g1 - g0, -g0};
             ng1[tid] = -g1;
         }
         __syncthreads();
@@ -105,10 +106,12 @@ __global__ __launch_bounds__(NT, NB16 <= 3 ? 4 : 2) void k_eq_bwd_cx(Lay l, cons
             float rs[NB16], nrho[NB16], sig[NB16], ca[NB16], cs[NB16], cd[NB16];
 #pragma unroll
             for (int ib = 0; ib < NB16; ++ib) {
-                const float xa = pa[ib][4 * s * S], xb = pb[ib][4 * s * S];
-                rs[ib] = gg.x * xa + gg.y * xb;      // rho + sigma
-                sig[ib] = gg.z * xa + gg.w * xb;     // g1 Ya - g0 Yb
-                nrho[ib] = gg.w * xa + n1 * xb;      // -(g0 Ya + g1 Yb)
+                const f2 x = pa[ib][4 * s * S];
+                const float xa = x.x, xb = x.y;
+                const f2 t = f2{gg.x, gg.y} * xa + f2{gg.z, gg.w} * xb;   // (rho + sigma, sigma = g1 Ya - g0 Yb)
+                rs[ib] = t.x;
+                sig[ib] = t.y;
+                nrho[ib] = fmaf(gg.w, xa, n1 * xb);  // -(g0 Ya + g1 Yb)
                 ca[ib] = xa;
                 cs[ib] = xa + xb;
                 cd[ib] = xa - xb;

@@ -350,7 +350,7 @@ __device__ __forceinline__ void eq_cmac_v(eq_f2& acc, eq_f2 k, eq_f2 y) {
 }
 
 template <int T>
-__global__ __launch_bounds__(NT, T <= 25 ? 4 : T <= 31 ? 3 : 2) void k_eq_fwd_sym(Lay l, const float* __restrict__ y,
+__global__ __launch_bounds__(NT, T <= 25 ? 4 : 3) void k_eq_fwd_sym(Lay l, const float* __restrict__ y,
                                                                               const float* __restrict__ ws, float* __restrict__ xhat) {
     extern __shared__ float sm[];
     float* tile = sm;
@@ -441,7 +441,7 @@ static int eqcxb_allow_lds(K kernel, int bytes) {
 int launch_eq_fwd_cxb(const Lay& l, const float* y, const float* ws, float* xhat, hipStream_t st) {
     int nblk = (int)((l.sym_cnt + EQ_TB - 1) / EQ_TB);
     if (l.eqsym_t && !(l.flags & V2VAE_FLAG_EQ_MFMA_FWD)) {
-        const int per_cu = l.eqsym_t <= 25 ? 4 : l.eqsym_t <= 31 ? 3 : 2;   // resident workgroups per CU (launch bounds)
+        const int per_cu = l.eqsym_t <= 25 ? 4 : 3;  // resident workgroups per CU (launch bounds)
         const int nsy = l.eqsym_t <= 31 ? 2 : 1;                            // symbols per thread
         nblk = (nblk + nsy - 1) / nsy;
         const int nb = nblk < per_cu * CX_BLOCKS ? nblk : per_cu * CX_BLOCKS;
