@@ -29,7 +29,7 @@ constexpr int CX_REC = 576;          // floats per (workgroup, phase) record of 
 constexpr int CX_IMG = 2112;         // floats of the block-tile kernel's LDS image of its 32x32 accumulator tile (+ vectors)
 constexpr int SUM_CHUNKS = 32;       // first-stage groups of the two-stage partial-record sums
 constexpr int CX_BLOCKS = 256;       // one workgroup per CU (the LDS image takes most of a CU)
-constexpr int CXB_TWB = 256;         // windows per phase per block tile of the blocked kernel
+constexpr int CXB_TWB = 512;         // windows per phase per block tile of the blocked kernel
 constexpr int CXB_TPX = 35;          // row pitch of its transposing buffer when an extra tap rides along (columns 32, 33)
 constexpr int CX_MAXLAG = 48;        // lagged products kept for sum s s^T (largest blocked tap count)
 constexpr int G2C_D = 4 + 2 * (2 * CX_MAXLAG + 8);   // offset of the real coefficients D[lag] in the table at Lay::o_g2c
