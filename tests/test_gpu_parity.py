@@ -176,7 +176,8 @@ def test_complex_step_matches_oracle(L, S, l1, l2, B, M):
 
 @pytest.mark.parametrize("L,S,l1,l2,B,M", [(41, 2, 9, 5, 700, 4), (25, 1, 7, 5, 600, 4), (33, 1, 5, 3, 500, 2),
                                            (65, 2, 9, 5, 1100, 4), (95, 2, 7, 0, 800, 4), (33, 2, 5, 3, 900, 4),
-                                           (17, 1, 3, 3, 300, 2), (64, 2, 9, 5, 700, 4)])
+                                           (17, 1, 3, 3, 300, 2), (64, 2, 9, 5, 700, 4), (65, 2, 9, 5, 97, 4), (33, 1, 3, 3, 41, 2),
+                                           (65, 2, 5, 5, 4500, 2)])
 def test_complex_long_channel_blocked_kernel_matches_oracle(L, S, l1, l2, B, M):
     """16 < active taps per phase <= 48: the blocked matrix-core ELBO kernel (2 or 3 blocks of 16 taps, both phase counts; 17 and
     33 taps run as 1 and 2 blocks plus one tap on the side), several tiles and a ragged last one, against the fp64 autograd
