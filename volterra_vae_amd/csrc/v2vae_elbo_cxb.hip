@@ -5,14 +5,15 @@
 // Same mathematics and orientation as the <= 16-tap kernel (v2vae_elbo_cx.hip: windows on the lanes, taps in the
 // accumulator registers), with the taps cut into NB blocks of 16:
 //     [P | Q](xb)   = sum_jb [mu_a | mu_b](jb) . [[Hr, Hi], [-Hi, Hr]](jb, xb)       16 MFMA 32x32x2 per block pair
-//     T(xb)         = sum_jb s(jb) . |H|^2(jb, xb)                                     8
 //     [HWa|HWb](xb) = sum_jb [alpha | beta](jb) . [[Hr, -Hi], [Hi, Hr]](jb, xb)       16
+//     (no (H.H) s product: that term of E and its variance gradient are lagged-product sums formed by k_g2_cx)
 //     dE/dHr(xb,jb) += rho^T mu_a + sigma^T mu_b,  dE/dHi(xb,jb) += sigma^T mu_a - rho^T mu_b
 //                                                                   4 x 8 MFMA 16x16x4 (4 accumulator registers each)
 // The NB^2 x 40 constant A-operand images (92 KB per phase at NB = 3) do not fit LDS next to the tiles; they stay in
 // global memory (L2-resident, every wave streams the same sequence) and are fetched ahead of the MFMA chains.
-// One workgroup = 4 waves, ONE per SIMD: the per-block register images of z, w, ... (6 x 8 x NB) and the NB^2 gradient
-// tiles need the full 512-register budget; the kernel is bound by its MFMA chains (504 per 32-window slab at NB = 3).
+// One workgroup = 4 waves, ONE per SIMD: the per-block register images of z, w, ... and the NB^2 gradient tiles need the
+// full 512-register budget.  The per-(window, tap) algebra runs on tap PAIRS (accumulator registers 2 p, 2 p + 1 hold
+// neighbouring taps) in explicit two-wide arithmetic over structure-of-arrays moment planes.
 //
 // Tap counts of the form 16 NB + 1 (L = 65 at two samples per symbol: 33) would waste a whole block row and column on one
 // tap.  The XT = 1 instances keep NB blocks on the matrix cores and carry tap e = 16 NB on the side: as a contraction index

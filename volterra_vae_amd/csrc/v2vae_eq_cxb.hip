@@ -1,6 +1,8 @@
-// Complex second-order Volterra equaliser on the f32 matrix cores with the lag rows in NBL blocks of 32: the forward for every
-// kernel length up to 95 lags (NBL = 1, 2, 3), the backward for long kernels (31 < l2 <= 95; v2vae_eq_cx.hip has the one-block
-// backward).
+// Complex second-order Volterra equaliser.  Two forward kernels and the backward for the longest kernels:
+//  * k_eq_fwd_sym<T>: the forward in symmetric form on the vector pipe, up to 65 lags (the default; described at the kernel);
+//  * k_eq_fwd_cxb<NBL> / k_eq_bwd_cxb<NBL>: the f32 matrix cores with the lag rows in NBL blocks of 32: forward for 67 .. 95
+//    lags (and, on request, for any length up to 95: the A/B switch of the symmetric form), backward for 81 .. 95 lags
+//    (v2vae_eq_cx.hip has the backward on 16-lag blocks up to 79 lags).
 //
 // xhat_b = sum_j k1[j] y[bS + j - p1] + Y_b^T K Y_b,  K = k2 + k2^T complex symmetric, Y_b[x] = y[bS + p2 - x]
 // (lib/torch_components.py:79-96 on complex samples).
