@@ -114,8 +114,11 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
     float* s_c = s_stage + STG;                // [S][4][LEB]  h1r, h1i, diag Hr, diag Hi
     float* s_T = s_c + S * 4 * LEB;            // [NW][32 * TP]  transposing buffer of rho / sigma
     float* s_P = s_T + NW * 32 * TP;           // [S][NU][4][NSIG] anti-diagonal partial sums
-    float* s_rec = s_P + S * NU * 4 * NSIG;    // [S][REC]
-    float* s_xe = s_rec + S * REC;             // XT: [S][2][LEB] row e of the symmetrised kernel (Re, Im)
+    constexpr int TVP = 81;                    // row pitch of the second transposing buffer (odd multiple of 1 mod 64 spreads the banks)
+    constexpr int RECA = S * REC > NW * 32 * TVP ? S * REC : NW * 32 * TVP;
+    float* s_rec = s_P + S * NU * 4 * NSIG;    // [S][REC] after the last tile; before that [NW][32 windows][TVP]: per wave the four
+                                               // per-(window, tap) terms of the vector gradients of one tap block, to be transposed
+    float* s_xe = s_rec + RECA;                // XT: [S][2][LEB] row e of the symmetrised kernel (Re, Im)
     __shared__ double dred[NW];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -130,7 +133,6 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
     const int TS = TWB - l.kmax;
 
     for (int idx = tid; idx < S * 4 * LEB; idx += CXB_NT) s_c[idx] = ws[l.o_cxbc + idx];
-    for (int idx = tid; idx < S * REC; idx += CXB_NT) s_rec[idx] = 0.f;
     if (XT)
         for (int idx = tid; idx < S * 2 * LEB; idx += CXB_NT) {
             const int j = idx % LEB, rp = idx / LEB;
@@ -142,7 +144,10 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
     const float* cst = s_c + r * 4 * LEB;
     __syncthreads();
     f32x4 Gr[NB][NB], Gi[NB][NB];
-    f2 ghr[NB][4], ghi[NB][4], gdr[NB][4], gdi[NB][4];   // vector gradients of the tap pairs (2 p, 2 p + 1) of each block
+    // vector gradients (d/dh1 Re, Im; d/d diag H Re, Im), accumulated in the TRANSPOSED layout the 16x16 MFMAs read (lane = (tap
+    // lane & 15, window group lane >> 4)): one register per block and quantity instead of eight in the window-on-lane layout
+    float vacc[NB][4];
+    float* Tv = s_rec + wv * 32 * TVP;
 #pragma unroll
     for (int a = 0; a < NB; ++a) {
 #pragma unroll
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
 #pragma unroll
             for (int g = 0; g < 4; ++g) { Gr[a][b][g] = 0.f; Gi[a][b][g] = 0.f; }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { ghr[a][q] = 0.f; ghi[a][q] = 0.f; gdr[a][q] = 0.f; gdi[a][q] = 0.f; }
+        for (int q = 0; q < 4; ++q) vacc[a][q] = 0.f;
     }
     // extra tap e (XT): vector gradients, the (e, e) element, and row / column e of dE/dH in the transposed layout
     // (lane = (tap lane & 15, window group lane >> 4))
@@ -330,8 +335,6 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                     al[xb][p] = 2.f * (Sv * zp + ka * dr - kb * di);
                     be[xb][p] = 2.f * (Sv * zq + ka * di + kb * dr);
                     zP[xb][p] = zp; zQ[xb][p] = zq;
-                    gdr[xb][p] += (2.f * mo) * (ka * zp + kb * zq + gs * dr);
-                    gdi[xb][p] += (2.f * mo) * (ka * zq - kb * zp + gs * di);
                 }
                 BSTAMP(2);
             }
@@ -483,16 +486,23 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                     const int xl = cx_kk(2 * p, h);
                     const int slot = tsl + i + 16 * xb + xl;
                     const f2 ma = ld2(s_mu + slot), mb = ld2(s_mu + MS + slot), dvq = ld2(s_dv + slot);
+                    const f2 ka = ld2(s_ka + slot), kb = ld2(s_kb + slot), gs = ld2(s_gs + slot);
+                    const f2 dr = ld2(cst + 2 * LEB + 16 * xb + xl), di = ld2(cst + 3 * LEB + 16 * xb + xl);
+                    const f2 zp = zP[xb][p], zq = zQ[xb][p];
                     const f2 gr = 2.f * (e0 * ma + e1 * mb), gi = 2.f * (e1 * ma - e0 * mb);
-                    ghr[xb][p] += mo * (gr + al[xb][p]);
-                    ghi[xb][p] += mo * (gi + be[xb][p]);
-                    gdr[xb][p] += (mo * 2.f * e0) * dvq;
-                    gdi[xb][p] += (mo * 2.f * e1) * dvq;
+                    const f2 v0 = mo * (gr + al[xb][p]), v1 = mo * (gi + be[xb][p]);
+                    const f2 v2 = (2.f * mo) * (ka * zp + kb * zq + gs * dr + e0 * dvq);
+                    const f2 v3 = (2.f * mo) * (ka * zq - kb * zp + gs * di + e1 * dvq);
                     const f2 t0 = mo * (gr + 2.f * al[xb][p]), t1 = mo * (gi + 2.f * be[xb][p]);
                     Tb[i * TP + xl] = t0.x;
                     Tb[i * TP + xl + 1] = t0.y;
                     Tb[i * TP + 16 + xl] = t1.x;
                     Tb[i * TP + 16 + xl + 1] = t1.y;
+                    float* tv = Tv + i * TVP + xl;
+                    tv[0] = v0.x; tv[1] = v0.y;
+                    tv[16] = v1.x; tv[17] = v1.y;
+                    tv[32] = v2.x; tv[33] = v2.y;
+                    tv[48] = v3.x; tv[49] = v3.y;
                 }
                 __builtin_amdgcn_wave_barrier();
                 {
@@ -502,6 +512,14 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                     for (int st = 0; st < 8; ++st) {
                         ar[st] = Tb[(4 * st + kq) * TP + xa];
                         as[st] = Tb[(4 * st + kq) * TP + 16 + xa];
+                    }
+#pragma unroll
+                    for (int st = 0; st < 8; ++st) {
+                        const float* tv = Tv + (4 * st + kq) * TVP + xa;
+                        vacc[xb][0] += tv[0];
+                        vacc[xb][1] += tv[16];
+                        vacc[xb][2] += tv[32];
+                        vacc[xb][3] += tv[48];
                     }
                     if (XT) {   // column e of dE/dH: this lane's share of sum_w (rho, sigma)(w, x) mu(w + e)
 #pragma unroll
@@ -568,6 +586,8 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
 #endif
 
     // ---- one record per (block, phase): the waves of a phase add their tiles in a fixed order
+    for (int idx = tid; idx < S * REC; idx += CXB_NT) s_rec[idx] = 0.f;   // (the last tile ended with a workgroup barrier)
+    __syncthreads();
     float* img = s_rec + (size_t)r * REC;
     for (int w = 0; w < NWP; ++w) {
         if (wsub == w) {
@@ -581,16 +601,15 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                         img[a * LEB + b] += Gr[xb][jb][g];
                         img[(LEB + a) * LEB + b] += Gi[xb][jb][g];
                     }
+                {
+                    float v0 = vacc[xb][0], v1 = vacc[xb][1], v2 = vacc[xb][2], v3 = vacc[xb][3];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    float v0 = ghr[xb][q >> 1][q & 1], v1 = ghi[xb][q >> 1][q & 1], v2 = gdr[xb][q >> 1][q & 1], v3 = gdi[xb][q >> 1][q & 1];
-#pragma unroll
-                    for (int off = 1; off < 32; off <<= 1) {
+                    for (int off = 16; off < 64; off <<= 1) {   // over the four window groups
                         v0 += __shfl_xor(v0, off); v1 += __shfl_xor(v1, off);
                         v2 += __shfl_xor(v2, off); v3 += __shfl_xor(v3, off);
                     }
-                    if (i == 0) {
-                        const int x = 16 * xb + cx_kk(q, h);
+                    if (lane < 16) {
+                        const int x = 16 * xb + lane;
                         img[2 * LEB * LEB + 0 * LEB + x] += v0;
                         img[2 * LEB * LEB + 1 * LEB + x] += v1;
                         img[2 * LEB * LEB + 2 * LEB + x] += v2;

@@ -165,7 +165,8 @@ int make_layout(const v2vae_problem* p, Lay* out) {
             l.nblk_cxb = l.ntile_cxb < CX_BLOCKS ? l.ntile_cxb : CX_BLOCKS;
             const int ms = CXB_TWB + l.cxb_leb + 16, nsig = 32 + l.cxb_leb;
             l.lds_cxb = ((7 * ms + 2 * l.S * CXB_TWB) + l.S * 4 * l.cxb_leb + 4 * 32 * (l.cxb_xt ? CXB_TPX : CX_TP) +
-                         l.S * (CXB_TWB / 32) * 4 * nsig + l.S * l.cxb_rec + (l.cxb_xt ? l.S * 2 * l.cxb_leb : 0)) * 4;
+                         l.S * (CXB_TWB / 32) * 4 * nsig + (l.S * l.cxb_rec > 4 * 32 * 81 ? l.S * l.cxb_rec : 4 * 32 * 81) +
+                         (l.cxb_xt ? l.S * 2 * l.cxb_leb : 0)) * 4;   // records / per-wave [32][81] transposing buffers share memory
         }
         l.nblk_E = l.use_cx ? l.nblk_cx + G2_NE : (l.use_cxb ? l.nblk_cxb + G2_NE : l.nblk_elbo);   // + 1: the lagged-product term of E (k_g2_cx)
         if (!l.use_cx && !l.use_cxb && !generic_elbo_ok) return V2VAE_ESIZE;
