@@ -362,7 +362,10 @@ __global__ __launch_bounds__(NT, T <= 25 ? 4 : 3) void k_eq_fwd_sym(Lay l, const
     constexpr int NE = T * (T + 1) / 2 + T;
     const int64_t sym_hi = l.sym_lo + l.sym_cnt;
     const int64_t ntile = (l.sym_cnt + TB - 1) / TB;
-    const int tlen = l.tile_len + (NSY - 1) * EQ_TB * l.S;
+    // the instance reads T lags; table entries of lags from l2 on are zero, and T - l2 extra samples of left halo keep those
+    // reads inside the tile (finite values), so no lag needs a bounds check
+    const int xh = T - l.l2;
+    const int tlen = l.tile_len + xh + (NSY - 1) * EQ_TB * l.S;
     for (int64_t t = blockIdx.x; t < ntile; t += gridDim.x) {
         const int64_t b0 = l.sym_lo + t * TB;
         // The table base is re-declared opaque (a scalar register pair) per tile: the table does not depend on the tile, and
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(NT, T <= 25 ? 4 : 3) void k_eq_fwd_sym(Lay l, const
         const ctab_p tab = (ctab_p)tab_generic;
         __syncthreads();
         {   // a tile inside the sequence and the local sample block (all but the ends) is copied without per-element checks
-            const int64_t g0 = b0 * l.S - l.hl, loc0 = g0 - l.y_lo;
+            const int64_t g0 = b0 * l.S - l.hl - xh, loc0 = g0 - l.y_lo;
             const bool inside = g0 >= 0 && g0 + tlen <= l.n_glob && loc0 >= 0 && loc0 + tlen <= l.y_len;   // uniform
             for (int c = 0; c < l.ns; ++c) {
                 const float* __restrict__ src = y + (int64_t)c * l.y_stride + loc0;
@@ -393,12 +396,9 @@ __global__ __launch_bounds__(NT, T <= 25 ? 4 : 3) void k_eq_fwd_sym(Lay l, const
         eq_f2 yv[NSY][T];
 #pragma unroll
         for (int n = 0; n < NSY; ++n) {
-            const int base = (tid + n * EQ_TB) * l.S + l.hl + l.p2;
+            const int base = (tid + n * EQ_TB) * l.S + l.hl + xh + l.p2;
 #pragma unroll
-            for (int x = 0; x < T; ++x) {
-                const bool in = x < l.l2;
-                yv[n][x] = in ? eq_f2{tile[base - x], tile[tlen + base - x]} : eq_f2{0.f, 0.f};
-            }
+            for (int x = 0; x < T; ++x) yv[n][x] = eq_f2{tile[base - x], tile[tlen + base - x]};
         }
         eq_f2 out[NSY], u[NSY];
 #pragma unroll
@@ -447,7 +447,7 @@ int launch_eq_fwd_cxb(const Lay& l, const float* y, const float* ws, float* xhat
         const int nsy = l.eqsym_t <= 31 ? 2 : 1;                            // symbols per thread
         nblk = (nblk + nsy - 1) / nsy;
         const int nb = nblk < per_cu * CX_BLOCKS ? nblk : per_cu * CX_BLOCKS;
-        const int lds = l.ns * (l.tile_len + (nsy - 1) * EQ_TB * l.S) * 4;
+        const int lds = l.ns * (l.tile_len + (l.eqsym_t - l.l2) + (nsy - 1) * EQ_TB * l.S) * 4;
         if (l.eqsym_t == 9) hipLaunchKernelGGL(k_eq_fwd_sym<9>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat);
         else if (l.eqsym_t == 17) hipLaunchKernelGGL(k_eq_fwd_sym<17>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat);
         else if (l.eqsym_t == 25) hipLaunchKernelGGL(k_eq_fwd_sym<25>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat);
