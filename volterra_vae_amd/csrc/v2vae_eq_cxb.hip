@@ -379,16 +379,17 @@ __global__ __launch_bounds__(NT, T <= 25 ? 4 : 3) void k_eq_fwd_sym(Lay l, const
         {   // a tile inside the sequence and the local sample block (all but the ends) is copied without per-element checks
             const int64_t g0 = b0 * l.S - l.hl - xh, loc0 = g0 - l.y_lo;
             const bool inside = g0 >= 0 && g0 + tlen <= l.n_glob && loc0 >= 0 && loc0 + tlen <= l.y_len;   // uniform
-            for (int c = 0; c < l.ns; ++c) {
-                const float* __restrict__ src = y + (int64_t)c * l.y_stride + loc0;
-                float* dst = tile + c * tlen;
-                if (inside) {
-                    for (int i = tid; i < tlen; i += NT) dst[i] = src[i];
-                } else {
-                    for (int i = tid; i < tlen; i += NT) {
-                        const int64_t g = g0 + i, loc = loc0 + i;
-                        dst[i] = (g >= 0 && g < l.n_glob && loc >= 0 && loc < l.y_len) ? src[i] : 0.f;
-                    }
+            // the two streams interleaved: one 8-byte LDS read per sample
+            const float* __restrict__ sa = y + loc0;
+            const float* __restrict__ sb = y + l.y_stride + loc0;
+            eq_f2* dst = reinterpret_cast<eq_f2*>(tile);
+            if (inside) {
+                for (int i = tid; i < tlen; i += NT) dst[i] = eq_f2{sa[i], sb[i]};
+            } else {
+                for (int i = tid; i < tlen; i += NT) {
+                    const int64_t g = g0 + i, loc = loc0 + i;
+                    const bool in = g >= 0 && g < l.n_glob && loc >= 0 && loc < l.y_len;
+                    dst[i] = in ? eq_f2{sa[i], sb[i]} : eq_f2{0.f, 0.f};
                 }
             }
         }
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(NT, T <= 25 ? 4 : 3) void k_eq_fwd_sym(Lay l, const
         for (int n = 0; n < NSY; ++n) {
             const int base = (tid + n * EQ_TB) * l.S + l.hl + xh + l.p2;
 #pragma unroll
-            for (int x = 0; x < T; ++x) yv[n][x] = eq_f2{tile[base - x], tile[tlen + base - x]};
+            for (int x = 0; x < T; ++x) yv[n][x] = reinterpret_cast<const eq_f2*>(tile)[base - x];
         }
         eq_f2 out[NSY], u[NSY];
 #pragma unroll
