@@ -76,6 +76,82 @@ def _oracle_on_float32_inputs(g, S, lin):
     return out
 
 
+@pytest.mark.parametrize("name", [n for n in STEP32 if "S3" not in n])
+def test_real_step_on_matrix_core_elbo_kernel_matches_reference_golden(name):
+    """The real model through the matrix-core ELBO kernel (a zero quadrature stream plus the diagonal-quirk terms; the default from
+    2^15 symbols on, forced here): the kernel the complex headline shape runs, pinned by the reference's own goldens."""
+    from volterra_vae_amd import _lib
+    from volterra_vae_amd.ops import Plan
+    g32 = np.load(os.path.join(GOLDEN, f"v2vae_real_step_{name}.npz"))
+    g64 = np.load(os.path.join(GOLDEN, f"v2vae_real_step_{name[:-3]}f64.npz"))
+    S, L, l1, l2, B = (int(g32[k]) for k in ("S", "L", "l1", "l2", "B"))
+    lin = bool(int(g32["linear_eq"]))
+    levels = dev(g32["constellation"][None, :])
+    prior = torch.ones_like(levels) / levels.shape[1]
+    y = dev(g32["rx"][None, :])
+    outs = {}
+    for tag, flags in (("mfma", _lib.FLAG_REAL_MFMA), ("generic", 0)):
+        plan = Plan(ns=1, sps=S, l1=l1, pad1=(l1 - 1) // 2 if lin else l1 // 2, l2=0 if lin else l2, L=L,
+                    C_levels=levels.shape[1], n_glob=B * S, device="cuda", flags=flags)
+        k1 = dev(g32["eq_w"].reshape(-1)) if lin else dev(g32["k1"])
+        k2 = None if lin else dev(g32["k2"])
+        nv = dev(np.array([float(g32["noise_variance_in"])]))
+        outs[tag] = run_step(plan, y, dev(g32["h1"]), dev(g32["h2"]), k1, k2, levels, prior, dev(g32["noise_scaling"][None, :]), nv, True)
+    out = outs["mfma"]
+    def chk(ours, key, flat=False):
+        r64 = np.asarray(g64[key], dtype=np.float64)
+        if flat:
+            r64 = r64.reshape(-1)
+        e64 = rel(ours, r64)
+        print(f"{name} {key}: matrix-core path vs fp64 ref {e64:.2e}")
+        assert e64 < TOL, f"{key}: {e64:.2e} vs fp64 reference"
+    chk(np.array([out["loss"]]), "loss")
+    chk(np.array([out["E"]]), "E")
+    chk(out["g"]["h1"], "g_h1")
+    chk(out["g"]["h2"], "g_h2")
+    if not int(g32["no_scaling"]):
+        chk(out["g"]["sc"][0], "g_noise_scaling")
+    if lin:
+        chk(out["g"]["k1"], "g_eq_w", flat=True)
+    else:
+        chk(out["g"]["k1"], "g_k1")
+        chk(out["g"]["k2"], "g_k2")
+    # and the two ELBO kernels against each other
+    gen = outs["generic"]
+    assert abs(out["E"] - gen["E"]) < 2e-6 * abs(gen["E"])
+    for k in ("h1", "h2", "k1", "sc"):
+        assert rel(out["g"][k], gen["g"][k].cpu().numpy()) < 5e-6, k
+    assert rel(out["gx"], gen["gx"].cpu().numpy()) < 5e-6
+
+
+@pytest.mark.parametrize("L,S,l1,l2,B,M", [(15, 2, 25, 25, 40000, 4), (25, 2, 9, 5, 33000, 4), (13, 1, 5, 3, 50000, 2)])
+def test_real_large_batch_default_is_matrix_core_elbo_and_agrees_with_generic(L, S, l1, l2, B, M):
+    """From 2^15 owned symbols on the real model's ELBO runs on the matrix cores by default; the generic kernels (reference-pinned
+    by the goldens) on the same inputs are the check."""
+    from volterra_vae_amd import _lib
+    from volterra_vae_amd.ops import Plan
+    from volterra_vae_amd.synth import nonlinear_isi, pam_constellation
+    rng = np.random.default_rng(21)
+    rx, _ = nonlinear_isi(B, pam_constellation(M), S, 17.0, rng)
+    y = dev(np.real(rx)[None, :])
+    lv = np.arange(-(M - 1), M, 2).astype(float)[None, :]
+    levels, prior = dev(lv), dev(np.ones_like(lv) / M)
+    h1 = 0.1 * rng.standard_normal(L); h1[L // 2] += 1.0
+    h2 = 0.02 * rng.standard_normal((L, L))
+    k1 = 0.1 * rng.standard_normal(l1); k1[l1 // 2] += 1.0
+    k2 = 0.01 * rng.standard_normal((l2, l2))
+    sc = 1.0 + 0.2 * rng.random((1, M))
+    outs = []
+    for flags in (0, _lib.FLAG_GENERIC):
+        plan = Plan(ns=1, sps=S, l1=l1, pad1=l1 // 2, l2=l2, L=L, C_levels=M, n_glob=B * S, device="cuda", flags=flags)
+        o = run_step(plan, y, dev(h1), dev(h2), dev(k1), dev(k2), levels, prior, dev(sc), dev(np.array([0.06])))
+        outs.append(dict(E=float(o["E"]), loss=float(o["loss"]), gx=o["gx"].clone(), **{k: v.clone() for k, v in o["g"].items()}))
+    a, b = outs
+    assert abs(a["E"] - b["E"]) < 2e-6 * abs(b["E"]) and abs(a["loss"] - b["loss"]) < 2e-6 * abs(b["loss"])
+    for k in ("gx", "h1", "h2", "k1", "k2", "sc"):
+        assert rel(a[k], b[k].cpu().numpy()) < 5e-6, k
+
+
 @pytest.mark.parametrize("name", STEP32)
 def test_real_step_matches_reference_golden(name):
     from volterra_vae_amd.ops import Plan

@@ -21,17 +21,19 @@ OK, EINVAL, EHALO, ELAUNCH, ESIZE = 0, -1, -2, -3, -4
 _ERR = {EINVAL: "invalid argument / unsupported shape", EHALO: "local sample or symbol range does not cover the halo",
         ELAUNCH: "HIP launch error", ESIZE: "problem exceeds the kernels' on-chip tiling limits"}
 
-FLAG_GENERIC, FLAG_EQ_MFMA_FWD, FLAG_ELBO_TILES = 1, 2, 4
+FLAG_GENERIC, FLAG_EQ_MFMA_FWD, FLAG_ELBO_TILES, FLAG_REAL_MFMA = 1, 2, 4, 8
 
 
 def default_flags() -> int:
     """Kernel A/B switches for measurements and tooling, taken from the environment when a problem is set up
     (V2VAE_FORCE_GENERIC: generic FMA kernels everywhere; V2VAE_EQ_MFMA_FWD: matrix-core forward equaliser; V2VAE_ELBO_TILES:
-    block-tile instead of run matrix-core ELBO kernel).  The
+    block-tile instead of run matrix-core ELBO kernel; V2VAE_REAL_MFMA: the real model on the matrix-core ELBO kernel at every batch
+    size, not only from 2^15 symbols on).  The
     library itself never reads the environment: the choice travels in `Problem.flags`."""
     return (FLAG_GENERIC if os.environ.get("V2VAE_FORCE_GENERIC") else 0) | \
         (FLAG_EQ_MFMA_FWD if os.environ.get("V2VAE_EQ_MFMA_FWD") else 0) | \
-        (FLAG_ELBO_TILES if os.environ.get("V2VAE_ELBO_TILES") else 0)
+        (FLAG_ELBO_TILES if os.environ.get("V2VAE_ELBO_TILES") else 0) | \
+        (FLAG_REAL_MFMA if os.environ.get("V2VAE_REAL_MFMA") else 0)
 
 
 SCAL_E, SCAL_KL, SCAL_LOSS, SCAL_LAMBDA, SCAL_W, SCAL_COUNT = 0, 1, 2, 3, 4, 8

@@ -482,7 +482,11 @@ __host__ __device__ constexpr int cx3_lds_floats(int S, int NK) {
     return S * 2 * NK * 64 + S * 64 + CX3_NW * CX3_WAVE_F;
 }
 
-template <int S, int NK>
+// REAL: the real model (one stream).  The quadrature stream is identically zero - its samples read as zero, its moment planes are
+// zero-filled by the soft demapper, the imaginary planes of the tables are zero - and the three terms of the reference's
+// diagonal quirk (lib/real_equalization.py:869: the mean uses diag(h2) where the second moment uses the diagonal d = 2 diag(h2) of
+// the symmetrised kernel) are added: with T_n = y'_n sum_x v_{n+x} d_x,  E += T_n,  dE/dv_{n+x} += y'_n d_x,  dE/dd_x += y'_n v_{n+x}.
+template <int S, int NK, bool REAL>
 __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __restrict__ y, float* __restrict__ ws) {
     extern __shared__ __align__(16) float sm[];
     constexpr int WT = CX3_WT, MS = CX3_MS, TP = CX_TP, NW = CX3_NW;
@@ -561,7 +565,7 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
     auto load_y = [&](int64_t t, int o) -> float {
         const int64_t n = t * S + r;
         float v = 0.f;
-        if (t < b && n >= 0 && n < l.W) {
+        if ((!REAL || o == 0) && t < b && n >= 0 && n < l.W) {
             const int64_t loc = l.pre + n - l.y_lo;
             if (loc >= 0 && loc < l.y_len) v = y[(int64_t)o * l.y_stride + loc];
         }
@@ -686,6 +690,7 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
                 zz[p] = z2;
                 dvv[p] = dv;
                 gdr[p] += (2.f * mo) * (ka * zp + kb * zq + gs * dr);
+                if (REAL) gdr[p] += (mo * y0) * Sv;
                 gdi[p] += (2.f * mo) * (ka * zq - kb * zp + gs * di);
             }
             if (NK != 13) { a0 = a0v.x + a0v.y; a1 = a1v.x + a1v.y; }
@@ -696,7 +701,7 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
             sd0 += __shfl_xor(sd0, 32); sd1 += __shfl_xor(sd1, 32);
             vs += __shfl_xor(vs, 32);
             float e0 = a0 + q0 + sd0 - y0, e1 = a1 + q1 + sd1 - y1;
-            if (own && h == 0) Eacc += (double)(e0 * e0 + e1 * e1 + vs);
+            if (own && h == 0) Eacc += (double)(e0 * e0 + e1 * e1 + vs + (REAL ? y0 * sd0 : 0.f));
             e0 *= mv; e1 *= mv;
 
             STAMP(2);
@@ -732,7 +737,9 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
                 const f2 ed = 2.f * (e0 * dr + e1 * di);
                 const f2 da0 = (2.f * mv) * (e0 * zp + e1 * zq + f2{HW[2 * p], HW[2 * p + 1]});
                 const f2 db0 = (2.f * mv) * (e1 * zp - e0 * zq + f2{HW[2 * p + 8], HW[2 * p + 9]});
-                const f2 da1 = mv * (zz[p] + ed), db1 = mv * (zz[p] - ed);
+                f2 da1 = mv * (zz[p] + ed);
+                const f2 db1 = mv * (zz[p] - ed);
+                if (REAL) da1 += (mv * y0) * dr;
                 Bd[x * 32 + i] = f32x4{da0.x, db0.x, da1.x, db1.x};
                 Bd[(x + 1) * 32 + i] = f32x4{da0.y, db0.y, da1.y, db1.y};
             }
@@ -955,7 +962,9 @@ __global__ __launch_bounds__(NT, 5) void k_g2_cx(Lay l, float* __restrict__ ws) 
         for (int it = (int)blockIdx.x + G2_NE * (int)threadIdx.x; it < S * LE * LE; it += G2_NE * NT) {
             const int r = it / (LE * LE), rem = it - r * LE * LE;
             const int x = rem / LE, j = rem - x * LE;
-            const float hh = ws[l.o_HHc + ((size_t)(r * 2 + 0) * LTp + x) * LTp + j] + ws[l.o_HHc + ((size_t)(r * 2 + 1) * LTp + x) * LTp + j];
+            // |H_xj|^2 from the squared stacked tables: [phase][output 0 / 1][tap][tap] (Re^2 + Im^2); the real model has one output
+            const float hh = l.cx_real ? ws[l.o_HHc + ((size_t)r * LTp + x) * LTp + j]
+                                       : ws[l.o_HHc + ((size_t)(r * 2 + 0) * LTp + x) * LTp + j] + ws[l.o_HHc + ((size_t)(r * 2 + 1) * LTp + x) * LTp + j];
             const float ps = psum_value(l, ws, s_tot, r, x, j);
             ws[l.o_psv + it] = ps;   // kept for the chain rule of dE/dH
             v += 2.0 * (double)hh * (double)ps;
@@ -1052,10 +1061,13 @@ __global__ __launch_bounds__(NT, 5) void k_g2_cx(Lay l, float* __restrict__ ws) 
             const int x = rem / LE, j = rem - x * LE;
             const int64_t n = (m - x) * S + r;
             if (n < 0 || n >= l.W) continue;
-            const float* Hr = ws + l.o_Hc + (size_t)(r * 2 + 0) * LTp * LTp;
-            const float* Hi = ws + l.o_Hc + (size_t)(r * 2 + 1) * LTp * LTp;
-            const float dr = Hr[x * LTp + x], di = Hi[x * LTp + x];
-            const float hr = Hr[x * LTp + j], hi = Hi[x * LTp + j];
+            // stacked tables [phase][output][tap][tap]: outputs 0 / 1 restricted to the taps of stream 0 are Re / Im; the real model
+            // has one output and no imaginary part
+            const int no = l.cx_real ? 1 : 2;
+            const float* Hr = ws + l.o_Hc + (size_t)(r * no + 0) * LTp * LTp;
+            const float* Hi = ws + l.o_Hc + (size_t)(r * no + 1) * LTp * LTp;
+            const float dr = Hr[x * LTp + x], di = l.cx_real ? 0.f : Hi[x * LTp + x];
+            const float hr = Hr[x * LTp + j], hi = l.cx_real ? 0.f : Hi[x * LTp + j];
             const int64_t mm = m - x + j;
             float ua = 0.f, ub = 0.f, sv = 0.f;
             if (mm >= l.sym_lo && mm < sym_hi) {
@@ -1067,7 +1079,8 @@ __global__ __launch_bounds__(NT, 5) void k_g2_cx(Lay l, float* __restrict__ ws) 
             gi += 4.f * (dr * ci - di * cr);
             gt += 4.f * (hr * hr + hi * hi) * sv;
             if (j == 0) {
-                const float h1r = ws[l.o_h1c + (size_t)(r * 2 + 0) * LTp + x], h1i = ws[l.o_h1c + (size_t)(r * 2 + 1) * LTp + x];
+                const float h1r = ws[l.o_h1c + (size_t)(r * no + 0) * LTp + x];
+                const float h1i = l.cx_real ? 0.f : ws[l.o_h1c + (size_t)(r * no + 1) * LTp + x];
                 gr += 2.f * (dr * h1r + di * h1i);
                 gi += 2.f * (dr * h1i - di * h1r);
                 g3 += dr * dr + di * di;
@@ -1099,7 +1112,8 @@ __global__ __launch_bounds__(NT) void k_chain_channel_cx(Lay l, const float* __r
                                                          const float* __restrict__ grad_scale, float* __restrict__ g_h1,
                                                          float* __restrict__ g_h2) {
     const float lam = (float)scal[V2VAE_SCAL_LAMBDA] * (grad_scale ? grad_scale[0] : 1.f);
-    const int L = l.L, n1 = 2 * L, n2 = 2 * L * L;
+    const int np = l.cx_real ? 1 : 2;   // parameter planes (Re, Im; the real model has one)
+    const int L = l.L, n1 = np * L, n2 = np * L * L;
     auto compact = [&](int tap, int* r, int* x) {
         int rr = (tap - (L - 1)) % l.S;
         if (rr < 0) rr += l.S;
@@ -1154,8 +1168,12 @@ int launch_elbo_cx(const Lay& l, const float* y, float* ws, hipStream_t st) {
     }
     const bool k13 = l.LE <= 13;
     const int lds = cx3_lds_floats(l.S, k13 ? 13 : 16) * 4;
-    if (l.S == 1) return k13 ? launch_cx(k_elbo_cx3<1, 13>, l, lds, y, ws, st) : launch_cx(k_elbo_cx3<1, 16>, l, lds, y, ws, st);
-    return k13 ? launch_cx(k_elbo_cx3<2, 13>, l, lds, y, ws, st) : launch_cx(k_elbo_cx3<2, 16>, l, lds, y, ws, st);
+    if (l.cx_real) {
+        if (l.S == 1) return k13 ? launch_cx(k_elbo_cx3<1, 13, true>, l, lds, y, ws, st) : launch_cx(k_elbo_cx3<1, 16, true>, l, lds, y, ws, st);
+        return k13 ? launch_cx(k_elbo_cx3<2, 13, true>, l, lds, y, ws, st) : launch_cx(k_elbo_cx3<2, 16, true>, l, lds, y, ws, st);
+    }
+    if (l.S == 1) return k13 ? launch_cx(k_elbo_cx3<1, 13, false>, l, lds, y, ws, st) : launch_cx(k_elbo_cx3<1, 16, false>, l, lds, y, ws, st);
+    return k13 ? launch_cx(k_elbo_cx3<2, 13, false>, l, lds, y, ws, st) : launch_cx(k_elbo_cx3<2, 16, false>, l, lds, y, ws, st);
 }
 
 // what needs only the moments and runs right after the soft demapper: lagged products of s = v_a + v_b, and the gradients
@@ -1174,7 +1192,7 @@ void launch_psum_cx(const Lay& l, float* ws, hipStream_t st) {
 
 void launch_chain_channel_cx(const Lay& l, float* ws, const double* scal, const float* grad_scale, float* g_h1, float* g_h2,
                              hipStream_t st) {
-    const int n = 2 * l.L + 2 * l.L * l.L;
+    const int n = (l.cx_real ? 1 : 2) * (l.L + l.L * l.L);
     hipLaunchKernelGGL(k_chain_channel_cx, dim3((n + NT - 1) / NT), dim3(NT), 0, st, l, (const float*)ws, scal, grad_scale, g_h1, g_h2);
 }
 

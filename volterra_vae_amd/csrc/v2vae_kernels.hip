@@ -25,7 +25,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     if (!p || !out) return V2VAE_EINVAL;
     Lay l{};
     l.ns = p->ns; l.S = p->sps;
-    if (p->flags & ~(V2VAE_FLAG_GENERIC | V2VAE_FLAG_EQ_MFMA_FWD | V2VAE_FLAG_ELBO_TILES) || p->reserved != 0) return V2VAE_EINVAL;
+    if (p->flags & ~(V2VAE_FLAG_GENERIC | V2VAE_FLAG_EQ_MFMA_FWD | V2VAE_FLAG_ELBO_TILES | V2VAE_FLAG_REAL_MFMA) || p->reserved != 0) return V2VAE_EINVAL;
     l.flags = p->flags;
     if (p->mode < 0 || p->mode > 3) return V2VAE_EINVAL;
     l.chan = p->mode >= 2 ? p->mode - 1 : 0;  // modes 2, 3: real path with a polynomial channel model
@@ -137,6 +137,11 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     }
     // ---- matrix-core ELBO path: complex model, <= 16 active taps per stream and phase, S in {1, 2}
     l.use_cx = (l.mode == 1 && l.LE <= 16 && l.S <= 2 && !(l.flags & V2VAE_FLAG_GENERIC)) ? 1 : 0;
+    // the real model runs the same kernel on a zero quadrature stream (large batches; any batch on request)
+    l.cx_real = (l.mode == 0 && l.ns == 1 && l.chan == 0 && l.LE <= 16 && l.S <= 2 &&
+                 !(l.flags & (V2VAE_FLAG_GENERIC | V2VAE_FLAG_ELBO_TILES)) &&
+                 (l.own_cnt >= 32768 || (l.flags & V2VAE_FLAG_REAL_MFMA))) ? 1 : 0;
+    if (l.cx_real) l.use_cx = 1;
     l.cx_split = (l.use_cx && !(l.flags & V2VAE_FLAG_ELBO_TILES)) ? 1 : 0;
     {
         const int ts = 256 - l.kmax;
@@ -222,8 +227,8 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     l.xlo = (l.mode == 0 && l.ns == 1) ? 1 : 0;
     l.o_xhi = take(l.xlo ? l.sym_cnt : 0);
     l.o_xlo = take(l.xlo ? l.sym_cnt : 0);
-    l.o_mom = take((int64_t)l.ns * 4 * l.sym_cnt);
-    l.o_gmom = take((int64_t)l.ns * 4 * l.sym_cnt);
+    l.o_mom = take((int64_t)(l.cx_real ? 2 : l.ns) * 4 * l.sym_cnt);
+    l.o_gmom = take((int64_t)(l.cx_real ? 2 : l.ns) * 4 * l.sym_cnt);
     l.o_gpk = take(l.cx_split ? 12 * l.sym_cnt : 0);
     l.o_part_elbo = take((int64_t)l.nblk_elbo * l.rec_elbo);
     l.o_part_eq = take((int64_t)l.nblk_eq * l.rec_eq);
@@ -384,13 +389,14 @@ __device__ __forceinline__ void d_prep_tables(const GridCtx gc, Lay l, const flo
             const int rp = idx / 256, rem = idx - rp * 256;
             const int r = rp / 2, pl = rp - r * 2;
             const int a = tap_index(l, r, rem / 16), b = tap_index(l, r, rem % 16);  // compact taps of stream 0
-            ws[l.o_cxH + idx] = (rem / 16 < l.LE && rem % 16 < l.LE && a >= 0 && b >= 0) ? stacked_quad(l.mode, h2, l.L, pl, a, b) : 0.f;
+            // (real model on this path: the imaginary planes of every table are zero)
+            ws[l.o_cxH + idx] = (rem / 16 < l.LE && rem % 16 < l.LE && a >= 0 && b >= 0 && !(l.cx_real && pl)) ? stacked_quad(l.mode, h2, l.L, pl, a, b) : 0.f;
         }
         for (int idx = tid; idx < l.S * 2 * 16; idx += nth) {
             const int rp = idx / 16, x = idx - rp * 16;
             const int r = rp / 2, pl = rp - r * 2;
             const int a = tap_index(l, r, x);
-            ws[l.o_cxh1 + idx] = (x < l.LE && a >= 0) ? stacked_lin(l.mode, h1, l.L, pl, a) : 0.f;
+            ws[l.o_cxh1 + idx] = (x < l.LE && a >= 0 && !(l.cx_real && pl)) ? stacked_lin(l.mode, h1, l.L, pl, a) : 0.f;
         }
     }
     if ((l.use_cx || l.use_cxb) && h1) {
@@ -406,11 +412,12 @@ __device__ __forceinline__ void d_prep_tables(const GridCtx gc, Lay l, const flo
                 const int r = it / l.LE, x = it - r * l.LE;
                 const int a = tap_index(l, r, x);
                 if (a < 0) continue;
-                const float dr = stacked_quad(l.mode, h2, l.L, 0, a, a), di = stacked_quad(l.mode, h2, l.L, 1, a, a);
+                const float im = l.cx_real ? 0.f : 1.f;
+                const float dr = stacked_quad(l.mode, h2, l.L, 0, a, a), di = im * stacked_quad(l.mode, h2, l.L, 1, a, a);
                 float ar, ai;
                 if (c == ntap) {
                     ar = 2.f * stacked_lin(l.mode, h1, l.L, 0, a);
-                    ai = 2.f * stacked_lin(l.mode, h1, l.L, 1, a);
+                    ai = im * 2.f * stacked_lin(l.mode, h1, l.L, 1, a);
                     g3 += dr * dr + di * di;
                 } else {
                     const int j = x + c - K4;
@@ -418,7 +425,7 @@ __device__ __forceinline__ void d_prep_tables(const GridCtx gc, Lay l, const flo
                     const int b = tap_index(l, r, j);
                     if (b < 0) continue;
                     ar = stacked_quad(l.mode, h2, l.L, 0, a, b);
-                    ai = stacked_quad(l.mode, h2, l.L, 1, a, b);
+                    ai = im * stacked_quad(l.mode, h2, l.L, 1, a, b);
                     dd += ar * ar + ai * ai;
                 }
                 cr += dr * ar + di * ai;   // conj(d) * a
@@ -613,6 +620,10 @@ __device__ __forceinline__ void d_demap_moments(const GridCtx gc, Lay l, const f
                     klb += p.q[k] * __logf(fmaf(p.q[k], inv_pr[c][k], 1e-12f));  // argument >= 1e-12: the hardware log is exact enough
                 }
             if (in_kl) kl += (double)klb;
+        }
+        if (l.cx_real) {   // the zero quadrature stream the matrix-core ELBO kernels read
+            float* m = mom + (int64_t)4 * l.sym_cnt + i;
+            m[0] = 0.f; m[l.sym_cnt] = 0.f; m[2 * l.sym_cnt] = 0.f; m[3 * l.sym_cnt] = 0.f;
         }
     }
     const double s = block_sum_double(kl, red);

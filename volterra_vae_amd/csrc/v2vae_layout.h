@@ -73,6 +73,9 @@ struct Lay {
     // from the windows of phase 0 and of phase 1 (S = 2), [2] = (3rd-moment gradients a, b; the part of the variance gradient
     // that is a correlation of v_a + v_b; the 4th-cumulant gradient) from k_g2_cx; the per-symbol backward adds them up
     int cx_split;
+    // real model on the run kernel: the quadrature stream is identically zero (its moment planes are allocated and zero-filled by the
+    // soft demapper, its samples read as zero) and the kernel adds the terms of the diagonal quirk (dq = diag(h2), d = 2 diag(h2))
+    int cx_real;
     int64_t cx_rl, o_gpk;
     // blocked matrix-core ELBO path (complex, 16 < active taps per phase <= 48): taps in blocks of 16
     // cxb_nb blocks give the stride cxb_leb of tables and records; the kernel runs cxb_nbk blocks on the matrix cores plus cxb_xt
