@@ -744,13 +744,28 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
                 Bd[(x + 1) * 32 + i] = f32x4{da0.y, db0.y, da1.y, db1.y};
             }
             __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_sched_barrier(0);
             {
+                // the 16 row reads are requested in two batches of eight and summed pairwise: two LDS round trips instead of
+                // the sixteen dependent ones the register-pressure heuristics of the compiler would leave
+                f32x4 rr[16];
                 f32x4 sv = G4[tsl + lane];
 #pragma unroll
                 for (int x = 0; x < 16; ++x)   // row x, window lane - x (the zero vector when that is not a window of the slab)
-                    sv += Bd[(unsigned)(lane - x) < 32u ? x * 31 + lane : 16 * 32];
+                    rr[x] = Bd[(unsigned)(lane - x) < 32u ? x * 31 + lane : 16 * 32];
+#pragma unroll
+                for (int x = 0; x < 16; x += 2) sv += rr[x] + rr[x + 1];
                 G4[tsl + lane] = sv;
+                __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);    // G4 + rows 0..7
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {                         // a pair summed, the next pair requested
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_wave_barrier();
 
             STAMP(4);
