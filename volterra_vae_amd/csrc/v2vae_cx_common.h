@@ -53,6 +53,14 @@ __device__ __forceinline__ float cx_antidiag(const float (&v)[8]) {
     return a + cx_shr1(cx_shr1(cx_shr1(cx_shr1(b))));
 }
 
+// x(lane) + x(lane ^ 32) on every lane, on the vector pipe: after the swap `a` holds the lower half's value in both halves and
+// `b` the upper half's.
+__device__ __forceinline__ float cx_sum_halves(float x) {
+    float a = x, b = x;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 

@@ -551,8 +551,9 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
     // (combined once at the end: the sums are linear).  16x16x4 MFMAs, four windows per k-step.
     f32x4 K1 = {0.f, 0.f, 0.f, 0.f}, K2 = K1, K3 = K1;
     f2 ghr[4], ghi[4], gdr[4], gdi[4];  // vector gradients of the tap pairs (2 p, 2 p + 1)
+    f2 cdr[4], cdi[4];                  // diagonal of the kernel at this lane's tap pairs (both passes of a slab use it)
 #pragma unroll
-    for (int p = 0; p < 4; ++p) { ghr[p] = 0.f; ghi[p] = 0.f; gdr[p] = 0.f; gdi[p] = 0.f; }
+    for (int p = 0; p < 4; ++p) { ghr[p] = 0.f; ghi[p] = 0.f; gdr[p] = 0.f; gdi[p] = 0.f; cdr[p] = C2(2, p); cdi[p] = C2(3, p); }
     double Eacc = 0.0;
 
     // ---- this wave's run: symbols [a, b) of phase r
@@ -671,7 +672,7 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
                 const f2 P = f2{U[2 * p], U[2 * p + 1]}, Q = f2{U[2 * p + 8], U[2 * p + 9]};
                 const f2 ma = ld2(s_mu + slot), mb = ld2(s_mu + MS + slot), Sv = ld2(s_S + slot), dv = ld2(s_dv + slot);
                 const f2 ka = ld2(s_ka + slot), kb = ld2(s_kb + slot), gs = ld2(s_gs + slot);
-                const f2 hr = C2(0, p), hi = C2(1, p), dr = C2(2, p), di = C2(3, p);
+                const f2 hr = C2(0, p), hi = C2(1, p), dr = cdr[p], di = cdi[p];
                 const f2 zp = 2.f * P + hr, zq = 2.f * Q + hi;
                 if (NK != 13) {
                     a0v += hr * ma - hi * mb;
@@ -694,13 +695,13 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
                 gdi[p] += (2.f * mo) * (ka * zq - kb * zp + gs * di);
             }
             if (NK != 13) { a0 = a0v.x + a0v.y; a1 = a1v.x + a1v.y; }
-            float q0 = q0v.x + q0v.y, q1 = q1v.x + q1v.y;
-            float sd0 = sd0v.x + sd0v.y, sd1 = sd1v.x + sd1v.y, vs = vsv.x + vsv.y;
-            a0 += __shfl_xor(a0, 32); a1 += __shfl_xor(a1, 32);
-            q0 += __shfl_xor(q0, 32); q1 += __shfl_xor(q1, 32);
-            sd0 += __shfl_xor(sd0, 32); sd1 += __shfl_xor(sd1, 32);
-            vs += __shfl_xor(vs, 32);
-            float e0 = a0 + q0 + sd0 - y0, e1 = a1 + q1 + sd1 - y1;
+            // the two lane halves hold disjoint taps of the window: the per-window sums are completed by one half swap each
+            // (vector pipe; a shuffle would travel through the LDS pipeline and be waited for)
+            float sd0 = sd0v.x + sd0v.y;
+            const float vs = cx_sum_halves(vsv.x + vsv.y);
+            float e0 = cx_sum_halves((a0 + (q0v.x + q0v.y)) + sd0) - y0;
+            float e1 = cx_sum_halves((a1 + (q1v.x + q1v.y)) + (sd1v.x + sd1v.y)) - y1;
+            if (REAL) sd0 = cx_sum_halves(sd0);
             if (own && h == 0) Eacc += (double)(e0 * e0 + e1 * e1 + vs + (REAL ? y0 * sd0 : 0.f));
             e0 *= mv; e1 *= mv;
 
@@ -733,7 +734,7 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const int x = cx_kk(2 * p, h);
-                const f2 zp = zP[p], zq = zQ[p], dr = C2(2, p), di = C2(3, p);
+                const f2 zp = zP[p], zq = zQ[p], dr = cdr[p], di = cdi[p];
                 const f2 ed = 2.f * (e0 * dr + e1 * di);
                 const f2 da0 = (2.f * mv) * (e0 * zp + e1 * zq + f2{HW[2 * p], HW[2 * p + 1]});
                 const f2 db0 = (2.f * mv) * (e1 * zp - e0 * zq + f2{HW[2 * p + 8], HW[2 * p + 9]});
