@@ -770,12 +770,19 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
             __builtin_amdgcn_wave_barrier();
 
             STAMP(4);
-            // ---- rho / sigma (transposed through LDS), vector gradients
+            // ---- rho / sigma (transposed through LDS), vector gradients; the means are read again, all before the first
+            //      write (the compiler cannot tell the two LDS regions apart, so a read after a write would wait for it)
+            f2 mav[4], mbv[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int slot = tsl + i + cx_kk(2 * p, h);
+                mav[p] = ld2(s_mu + slot);
+                mbv[p] = ld2(s_mu + MS + slot);
+            }
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const int x = cx_kk(2 * p, h);
-                const int slot = tsl + i + x;
-                const f2 ma = ld2(s_mu + slot), mb = ld2(s_mu + MS + slot);
+                const f2 ma = mav[p], mb = mbv[p];
                 const f2 gr = 2.f * (e0 * ma + e1 * mb), gi = 2.f * (e1 * ma - e0 * mb);
                 ghr[p] += mo * (gr + al[p]);
                 ghi[p] += mo * (gi + be[p]);
@@ -787,7 +794,15 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
                 Ts[i * 17 + x] = t1.x;
                 Ts[i * 17 + x + 1] = t1.y;
             }
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);   // the eight pairs of means requested together
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 const int w = 4 * s + kq;   // window of this lane's k-slot; tap i16
@@ -797,6 +812,15 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
                 K2 = MFMA16(-rho, ma + mb, K2);
                 K3 = MFMA16(sig, ma - mb, K3);
             }
+            // operands of the first k-steps requested before the chain starts, the others while it runs
+            __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_wave_barrier();
             STAMP(5);
         }
