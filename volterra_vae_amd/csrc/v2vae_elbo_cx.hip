@@ -655,6 +655,14 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
                 else off = h ? MS : NK - 1;
                 U = MFMA32(Aop[s * 64], s_mu[tsl + i + off], U);
             }
+            // operands of the first steps requested before the chain starts, then two reads per step (the constant A operands
+            // and the means first, the moments of the per-tap algebra behind them)
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+            for (int s = 0; s < NK; ++s) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
 
             STAMP(1);
             // NK = 13: rows 13 of the product (upper lane half, accumulator slots 5 and 13) hold the first-order term of the window
