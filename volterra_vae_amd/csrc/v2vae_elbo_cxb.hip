@@ -338,12 +338,13 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                 }
                 BSTAMP(2);
             }
-            float a0 = a0v.x + a0v.y, a1 = a1v.x + a1v.y, q0 = q0v.x + q0v.y, q1 = q1v.x + q1v.y;
-            float sd0 = sd0v.x + sd0v.y, sd1 = sd1v.x + sd1v.y, vs = vsv.x + vsv.y;
-            a0 += __shfl_xor(a0, 32); a1 += __shfl_xor(a1, 32);
-            q0 += __shfl_xor(q0, 32); q1 += __shfl_xor(q1, 32);
-            sd0 += __shfl_xor(sd0, 32); sd1 += __shfl_xor(sd1, 32);
-            vs += __shfl_xor(vs, 32);
+            // the two lane halves hold disjoint taps of the window: the per-window sums are completed by one half swap each (vector
+            // pipe; a shuffle would travel through the LDS pipeline and be waited for).  a0 / a1 carry the whole residual sums
+            // from here on (first-order + quadratic + diagonal parts); q and sd stay zero and take the extra tap's terms.
+            float a0 = cx_sum_halves(((a0v.x + a0v.y) + (q0v.x + q0v.y)) + (sd0v.x + sd0v.y));
+            float a1 = cx_sum_halves(((a1v.x + a1v.y) + (q1v.x + q1v.y)) + (sd1v.x + sd1v.y));
+            float vs = cx_sum_halves(vsv.x + vsv.y);
+            float q0 = 0.f, q1 = 0.f, sd0 = 0.f, sd1 = 0.f;
             // extra tap e: its row of H X as a dot product over all taps (each half of the wave takes the taps it holds, the
             // halves are added), then the same per-(window, tap) algebra; both halves hold identical values from here on
             float zp_e = 0.f, zq_e = 0.f, al_e = 0.f, be_e = 0.f, z2_e = 0.f, dv_e = 0.f, ma_e = 0.f, mb_e = 0.f;
@@ -359,8 +360,7 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                         pe2 += ma * cr - mb * ci;
                         qe2 += ma * ci + mb * cr;
                     }
-                float pe = pe2.x + pe2.y, qe = qe2.x + qe2.y;
-                pe += __shfl_xor(pe, 32); qe += __shfl_xor(qe, 32);
+                float pe = cx_sum_halves(pe2.x + pe2.y), qe = cx_sum_halves(qe2.x + qe2.y);
                 const int slot = tsl + i + EX;
                 const float ma = s_mu[slot], mb = s_mu[MS + slot], Sv = s_S[slot], dv = s_dv[slot];
                 const float ka = s_ka[slot], kb = s_kb[slot], gs = s_gs[slot];
@@ -401,8 +401,7 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                         hwa2 += al[jb][p] * cr + be[jb][p] * ci;
                         hwb2 += be[jb][p] * cr - al[jb][p] * ci;
                     }
-                float hwa = hwa2.x + hwa2.y, hwb = hwb2.x + hwb2.y;
-                hwa += __shfl_xor(hwa, 32); hwb += __shfl_xor(hwb, 32);
+                float hwa = cx_sum_halves(hwa2.x + hwa2.y), hwb = cx_sum_halves(hwb2.x + hwb2.y);
                 hwa += al_e * xe[EX] + be_e * xe[LEB + EX];
                 hwb += be_e * xe[EX] - al_e * xe[LEB + EX];
                 const float dr = cst[2 * LEB + EX], di = cst[3 * LEB + EX];
@@ -481,28 +480,39 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                 }
                 BSTAMP(4);
                 // rho / sigma of this block (transposed through LDS), vector gradients
+                // (two tap pairs at a time, all their reads before their first write: the compiler cannot tell the LDS regions
+                // apart, so a read placed after a write is not moved above it and each pair would wait for its own reads)
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const int xl = cx_kk(2 * p, h);
-                    const int slot = tsl + i + 16 * xb + xl;
-                    const f2 ma = ld2(s_mu + slot), mb = ld2(s_mu + MS + slot), dvq = ld2(s_dv + slot);
-                    const f2 ka = ld2(s_ka + slot), kb = ld2(s_kb + slot), gs = ld2(s_gs + slot);
-                    const f2 dr = ld2(cst + 2 * LEB + 16 * xb + xl), di = ld2(cst + 3 * LEB + 16 * xb + xl);
-                    const f2 zp = zP[xb][p], zq = zQ[xb][p];
-                    const f2 gr = 2.f * (e0 * ma + e1 * mb), gi = 2.f * (e1 * ma - e0 * mb);
-                    const f2 v0 = mo * (gr + al[xb][p]), v1 = mo * (gi + be[xb][p]);
-                    const f2 v2 = (2.f * mo) * (ka * zp + kb * zq + gs * dr + e0 * dvq);
-                    const f2 v3 = (2.f * mo) * (ka * zq - kb * zp + gs * di + e1 * dvq);
-                    const f2 t0 = mo * (gr + 2.f * al[xb][p]), t1 = mo * (gi + 2.f * be[xb][p]);
-                    Tb[i * TP + xl] = t0.x;
-                    Tb[i * TP + xl + 1] = t0.y;
-                    Tb[i * TP + 16 + xl] = t1.x;
-                    Tb[i * TP + 16 + xl + 1] = t1.y;
-                    float* tv = Tv + i * TVP + xl;
-                    tv[0] = v0.x; tv[1] = v0.y;
-                    tv[16] = v1.x; tv[17] = v1.y;
-                    tv[32] = v2.x; tv[33] = v2.y;
-                    tv[48] = v3.x; tv[49] = v3.y;
+                for (int pp = 0; pp < 4; pp += 2) {
+                    f2 ma[2], mb[2], dvq[2], ka[2], kb[2], gs[2], dr[2], di[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int xl = cx_kk(2 * (pp + u), h);
+                        const int slot = tsl + i + 16 * xb + xl;
+                        ma[u] = ld2(s_mu + slot); mb[u] = ld2(s_mu + MS + slot); dvq[u] = ld2(s_dv + slot);
+                        ka[u] = ld2(s_ka + slot); kb[u] = ld2(s_kb + slot); gs[u] = ld2(s_gs + slot);
+                        dr[u] = ld2(cst + 2 * LEB + 16 * xb + xl); di[u] = ld2(cst + 3 * LEB + 16 * xb + xl);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int p = pp + u;
+                        const int xl = cx_kk(2 * p, h);
+                        const f2 zp = zP[xb][p], zq = zQ[xb][p];
+                        const f2 gr = 2.f * (e0 * ma[u] + e1 * mb[u]), gi = 2.f * (e1 * ma[u] - e0 * mb[u]);
+                        const f2 v0 = mo * (gr + al[xb][p]), v1 = mo * (gi + be[xb][p]);
+                        const f2 v2 = (2.f * mo) * (ka[u] * zp + kb[u] * zq + gs[u] * dr[u] + e0 * dvq[u]);
+                        const f2 v3 = (2.f * mo) * (ka[u] * zq - kb[u] * zp + gs[u] * di[u] + e1 * dvq[u]);
+                        const f2 t0 = mo * (gr + 2.f * al[xb][p]), t1 = mo * (gi + 2.f * be[xb][p]);
+                        Tb[i * TP + xl] = t0.x;
+                        Tb[i * TP + xl + 1] = t0.y;
+                        Tb[i * TP + 16 + xl] = t1.x;
+                        Tb[i * TP + 16 + xl + 1] = t1.y;
+                        float* tv = Tv + i * TVP + xl;
+                        tv[0] = v0.x; tv[1] = v0.y;
+                        tv[16] = v1.x; tv[17] = v1.y;
+                        tv[32] = v2.x; tv[33] = v2.y;
+                        tv[48] = v3.x; tv[49] = v3.y;
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();
                 {
