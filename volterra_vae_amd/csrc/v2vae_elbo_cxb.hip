@@ -449,34 +449,48 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                 }
                 if (XT) HW = MFMA32(xbufB[xb], h == 0 ? al_e : be_e, HW);
                 BSTAMP(3);
-                // anti-diagonal sums (symbol = window + tap) of the gradients of means (round 0) and variances (round 1), by
-                // lane shifts inside the wave (no LDS round trip); the partial of this tap block is added to the slab's record.
+                // anti-diagonal sums (symbol = window + tap) of the gradients of means and variances: the four quantities of a
+                // (window, tap) pair travel as one 4-vector through the wave's buffer (16 tap rows of 32 windows and a zero vector
+                // that every out-of-range read is pointed at; the memory is the second transposing buffer's, used after it), the
+                // 16 row reads are requested in batches and the partial of this tap block is added to the slab's record.
                 // The gradients of the 3rd moments and 4th cumulants do not need the residual: k_g2_cx has written them.
-#pragma unroll
-                for (int round = 0; round < 2; ++round) {
-                    float da[8], db[8];
+                {
+                    f32x4* Bd = reinterpret_cast<f32x4*>(Tv);
 #pragma unroll
                     for (int p = 0; p < 4; ++p) {
-                        const int x = 16 * xb + cx_kk(2 * p, h);
+                        const int xl = cx_kk(2 * p, h), x = 16 * xb + xl;
                         const f2 zp = zP[xb][p], zq = zQ[xb][p];
-                        f2 d0, d1;
-                        if (round == 0) {
-                            d0 = (2.f * mv) * (e0 * zp + e1 * zq + f2{HW[2 * p], HW[2 * p + 1]});
-                            d1 = (2.f * mv) * (e1 * zp - e0 * zq + f2{HW[2 * p + 8], HW[2 * p + 9]});
-                        } else {
-                            const f2 dr = ld2(cst + 2 * LEB + x), di = ld2(cst + 3 * LEB + x);
-                            const f2 ed = 2.f * (e0 * dr + e1 * di), zzp = zp * zp + zq * zq;
-                            d0 = mv * (zzp + ed);
-                            d1 = mv * (zzp - ed);
-                        }
-                        da[2 * p] = d0.x; da[2 * p + 1] = d0.y;
-                        db[2 * p] = d1.x; db[2 * p + 1] = d1.y;
+                        const f2 dr = ld2(cst + 2 * LEB + x), di = ld2(cst + 3 * LEB + x);
+                        const f2 ed = 2.f * (e0 * dr + e1 * di), zzp = zp * zp + zq * zq;
+                        const f2 d0 = (2.f * mv) * (e0 * zp + e1 * zq + f2{HW[2 * p], HW[2 * p + 1]});
+                        const f2 d1 = (2.f * mv) * (e1 * zp - e0 * zq + f2{HW[2 * p + 8], HW[2 * p + 9]});
+                        const f2 d2 = mv * (zzp + ed), d3 = mv * (zzp - ed);
+                        Bd[xl * 32 + i] = f32x4{d0.x, d1.x, d2.x, d3.x};
+                        Bd[(xl + 1) * 32 + i] = f32x4{d0.y, d1.y, d2.y, d3.y};
                     }
-                    const float sa = cx_antidiag(da), sb = cx_antidiag(db);
+                    if (lane == 0) Bd[16 * 32] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    f32x4 rr[16];
+#pragma unroll
+                    for (int x = 0; x < 16; ++x)   // row x, window lane - x (the zero vector when that is not a window of the slab)
+                        rr[x] = Bd[(unsigned)(lane - x) < 32u ? x * 31 + lane : 16 * 32];
+                    f32x4 sv = rr[0] + rr[1];
+#pragma unroll
+                    for (int x = 2; x < 16; x += 2) sv += rr[x] + rr[x + 1];
+                    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {                         // a pair summed, the next pair requested
+                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                     if (lane < 48) {
-                        Pu[(2 * round + 0) * NSIG + 16 * xb + lane] += sa;
-                        Pu[(2 * round + 1) * NSIG + 16 * xb + lane] += sb;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) Pu[c * NSIG + 16 * xb + lane] += sv[c];
                     }
+                    __builtin_amdgcn_wave_barrier();
                 }
                 BSTAMP(4);
                 // rho / sigma of this block (transposed through LDS), vector gradients
