@@ -1,0 +1,10 @@
+#!/bin/bash
+# GPU box: parity of the matrix-core kernels, then the headline bench line (per-kernel times).  Usage: bash tools/quick_elbo.sh <tag>
+set -e
+timeout -k 10 300 python -u -m pytest tests/test_gpu_parity.py tests/test_gpu_complex_linear.py -x -q --timeout 120 --timeout-method thread 2>&1 | tail -3
+timeout -k 10 120 python bench.py --no-cpu-baseline > gpurun_out/$1_bench.json
+python - <<PY
+import json
+d = json.load(open("gpurun_out/$1_bench.json"))
+print(round(d["ms_per_step"], 4), {k: round(v, 4) for k, v in d["kernel_ms"].items()})
+PY
