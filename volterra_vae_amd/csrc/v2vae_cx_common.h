@@ -61,6 +61,22 @@ __device__ __forceinline__ float cx_sum_halves(float x) {
     return a + b;
 }
 
+// Sum of x over the 64 lanes, valid on lane 63 only: shifts by 1, 2, 4, 8 inside the rows of 16 lanes (lanes without a source
+// add zero), then the row totals are passed on to the following rows (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows
+// 2 and 3).  Six additions on the vector pipe, no LDS round trip.
+__device__ __forceinline__ float cx_wave_sum_to_last(float x) {
+#define CX_DPP_ADD(ctrl, rmask)                                                                                                  \
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), (ctrl), (rmask), 0xF, (rmask) == 0xF))
+    CX_DPP_ADD(0x111, 0xF);   // row_shr:1
+    CX_DPP_ADD(0x112, 0xF);   // row_shr:2
+    CX_DPP_ADD(0x114, 0xF);   // row_shr:4
+    CX_DPP_ADD(0x118, 0xF);   // row_shr:8
+    CX_DPP_ADD(0x142, 0xA);   // row_bcast:15 -> rows 1 and 3 (the other rows keep old = 0, i.e. add nothing)
+    CX_DPP_ADD(0x143, 0xC);   // row_bcast:31 -> rows 2 and 3
+#undef CX_DPP_ADD
+    return x;
+}
+
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 

@@ -908,37 +908,62 @@ constexpr int PS_TILE = NT * PS_PER;    // symbols per tile; the tile's s values
 
 template <int NLAG>
 __global__ __launch_bounds__(NT) void k_psum_cx(Lay l, float* __restrict__ ws) {
+    static_assert(NLAG % 4 == 0, "a thread reads its values as 4-vectors");
     __shared__ double red[NT / 64][NLAG];
-    __shared__ float s_s[PS_TILE + NLAG];
+    __shared__ __align__(16) float s_s[PS_TILE + NLAG];
+    constexpr int NLD = (PS_TILE + NLAG + NT - 1) / NT;   // staged values per thread
+    constexpr int NV = (PS_PER + NLAG) / 4;               // 4-vectors a thread reads: its PS_PER consecutive symbols and the lags beyond
     const float* __restrict__ mom = ws + l.o_mom;
     double acc[NLAG];
 #pragma unroll
     for (int d = 0; d < NLAG; ++d) acc[d] = 0.0;
     const int64_t ntile = (l.own_cnt + PS_TILE - 1) / PS_TILE;
+    // the next tile's values travel in registers while this tile is summed (one exposed load latency per workgroup, not per tile)
+    float pre[NLD];
+    auto fetch = [&](int64_t m0) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = threadIdx.x + k * NT;
+            pre[k] = idx < PS_TILE + NLAG ? cx_s_at(l, mom, m0 + idx) : 0.f;
+        }
+    };
+    if ((int64_t)blockIdx.x < ntile) fetch(l.own_lo + (int64_t)blockIdx.x * PS_TILE);
     for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
         const int64_t m0 = l.own_lo + tile * PS_TILE;
         __syncthreads();
-        for (int i = threadIdx.x; i < PS_TILE + NLAG; i += NT) s_s[i] = cx_s_at(l, mom, m0 + i);
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = threadIdx.x + k * NT;
+            if (idx < PS_TILE + NLAG) s_s[idx] = pre[k];
+        }
         __syncthreads();
+        if (tile + gridDim.x < ntile) fetch(l.own_lo + (tile + gridDim.x) * PS_TILE);
+        // a thread owns PS_PER consecutive symbols: their values and the NLAG - 1 beyond them come as 4-vectors, the products
+        // are formed from registers
+        float sv[4 * NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(s_s + PS_PER * threadIdx.x + 4 * v);
+            sv[4 * v] = t[0]; sv[4 * v + 1] = t[1]; sv[4 * v + 2] = t[2]; sv[4 * v + 3] = t[3];
+        }
         float part[NLAG];
 #pragma unroll
         for (int d = 0; d < NLAG; ++d) part[d] = 0.f;
 #pragma unroll
         for (int q = 0; q < PS_PER; ++q) {
-            const int i = threadIdx.x + q * NT;
-            const float s0 = (m0 + i < l.own_lo + l.own_cnt) ? s_s[i] : 0.f;
+            const float s0 = (m0 + PS_PER * threadIdx.x + q < l.own_lo + l.own_cnt) ? sv[q] : 0.f;
 #pragma unroll
-            for (int d = 0; d < NLAG; ++d) part[d] = fmaf(s0, s_s[i + d], part[d]);
+            for (int d = 0; d < NLAG; ++d) part[d] = fmaf(s0, sv[q + d], part[d]);
         }
+        // the wave's total of the tile per lag (float, on the vector pipe: six lane-shift additions; lane 63 holds it), added to
+        // that lane's double accumulator
 #pragma unroll
-        for (int d = 0; d < NLAG; ++d) acc[d] += (double)part[d];
+        for (int d = 0; d < NLAG; ++d) acc[d] += (double)cx_wave_sum_to_last(part[d]);
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 63) {
 #pragma unroll
-    for (int d = 0; d < NLAG; ++d) {
-        double v = d <= l.kmax ? acc[d] : 0.0;
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0) red[wv][d] = v;
+        for (int d = 0; d < NLAG; ++d) red[wv][d] = d <= l.kmax ? acc[d] : 0.0;
     }
     __syncthreads();
     if (threadIdx.x < NLAG) {
