@@ -671,15 +671,23 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
                 a0 = h ? U[5] : 0.f; a1 = h ? U[13] : 0.f;
                 U[5] = h ? 0.f : U[5]; U[13] = h ? 0.f : U[13];
             }
-            // per-tap algebra on tap PAIRS (2 p, 2 p + 1)
+            // per-tap algebra on tap PAIRS (2 p, 2 p + 1).  One address register per PAIR of planes (the offset field of a
+            // two-float LDS read reaches the second plane of a pair but not the third): made opaque, or the compiler forms every
+            // plane address of every tap pair from one base with an addition of its own
+            // (pointers typed as LDS addresses: an opaque generic pointer would turn the reads into flat loads)
+            typedef const float __attribute__((address_space(3))) * lfloat_p;
+            lfloat_p b0 = (lfloat_p)(stg + tsl + i + 4 * h);
+            lfloat_p b2 = b0 + 2 * MS, b4 = b0 + 4 * MS, b6 = b0 + 6 * MS;
+            asm volatile("" : "+v"(b0), "+v"(b2), "+v"(b4), "+v"(b6));
+            auto ldl = [](lfloat_p q) { return f2{q[0], q[1]}; };
             f2 zP[4], zQ[4], al[4], be[4], zz[4], dvv[4];
             f2 a0v = 0.f, a1v = 0.f, q0v = 0.f, q1v = 0.f, sd0v = 0.f, sd1v = 0.f, vsv = 0.f;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                const int slot = tsl + i + cx_kk(2 * p, h);
+                const int xo = cx_kk(2 * p, 0);
                 const f2 P = f2{U[2 * p], U[2 * p + 1]}, Q = f2{U[2 * p + 8], U[2 * p + 9]};
-                const f2 ma = ld2(s_mu + slot), mb = ld2(s_mu + MS + slot), Sv = ld2(s_S + slot), dv = ld2(s_dv + slot);
-                const f2 ka = ld2(s_ka + slot), kb = ld2(s_kb + slot), gs = ld2(s_gs + slot);
+                const f2 ma = ldl(b0 + xo), mb = ldl(b0 + MS + xo), Sv = ldl(b2 + xo), dv = ldl(b2 + MS + xo);
+                const f2 ka = ldl(b4 + xo), kb = ldl(b4 + MS + xo), gs = ldl(b6 + xo);
                 const f2 hr = C2(0, p), hi = C2(1, p), dr = cdr[p], di = cdi[p];
                 const f2 zp = 2.f * P + hr, zq = 2.f * Q + hi;
                 if (NK != 13) {
@@ -783,9 +791,8 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
             f2 mav[4], mbv[4];
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                const int slot = tsl + i + cx_kk(2 * p, h);
-                mav[p] = ld2(s_mu + slot);
-                mbv[p] = ld2(s_mu + MS + slot);
+                mav[p] = ldl(b0 + cx_kk(2 * p, 0));
+                mbv[p] = ldl(b0 + MS + cx_kk(2 * p, 0));
             }
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
