@@ -473,7 +473,7 @@ constexpr int CX3_WT = 192;                 // windows per strip
 constexpr int CX3_MS = CX3_WT + 32;         // staged symbols per strip (16 used beyond the windows; 32 keeps the gradient
                                             // update of a slab, 64 lanes wide, inside the arrays)
 constexpr int CX3_NW = 8;                   // waves per workgroup
-constexpr int CX3_ADB = 16 * 32 + 4;        // 4-vectors of the anti-diagonal buffer (16 tap rows of 32 windows + a zero vector)
+constexpr int CX3_ADB = 16 * 32 + 4;        // 4-vectors of the anti-diagonal buffer (two planes of 8 tap-pair rows of 32 windows, a zero vector behind each)
 // floats of one wave's private LDS: 7 moment planes, the per-symbol gradient 4-vectors, the anti-diagonal buffer (which the
 // transposing buffer of the rho / sigma rows shares: the two are used one after the other within a slab)
 constexpr int CX3_WAVE_F = 7 * CX3_MS + 4 * CX3_MS + 4 * CX3_ADB;
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
             for (int e = lane; e < MS; e += 64) G4[e] = f32x4{0.f, 0.f, 0.f, 0.f};
             __builtin_amdgcn_wave_barrier();
             if (lane < 16) G4[lane] = carry;
-            Bd[16 * 32] = f32x4{0.f, 0.f, 0.f, 0.f};   // the zero vector (the transposing buffer overwrites nothing beyond 32 * TP floats)
+            if (lane < 2) Bd[8 * 32 + lane * (8 * 32 + 1)] = f32x4{0.f, 0.f, 0.f, 0.f};   // the zero vectors behind the two planes of the anti-diagonal buffer
             if (first) {   // start of the run: symbols [ts, ts + 16) directly, the first group of 32 into the registers
                 fetch32(ts - 16);
                 store32(-16, 16);
@@ -746,10 +746,14 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
 
             STAMP(3);
             // ---- gradients of the means and variances of symbol (window + tap): anti-diagonal sums of the slab through the
-            //      wave's zero-padded buffer of 4-vectors, then one update of the strip's per-symbol array (47 symbols)
+            //      wave's zero-padded buffer, then one update of the strip's per-symbol array (47 symbols).  A (window, tap pair)
+            //      writes its register pairs as they are: plane A holds (d mean_a, d mean_b) and plane B (d var_a, d var_b), each as
+            //      (even tap, odd tap) pairs; lane m sums the eight pair rows at window m - even tap, and the odd taps' sums, which
+            //      belong to the next symbol, move up one lane at the end.
+            constexpr int ZV = 8 * 32, PB = ZV + 1;   // the zero vector of plane A; plane B starts behind it and ends in its own
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                const int x = cx_kk(2 * p, h);
+                const int pr = cx_kk(2 * p, h) >> 1;
                 const f2 zp = zP[p], zq = zQ[p], dr = cdr[p], di = cdi[p];
                 const f2 ed = 2.f * (e0 * dr + e1 * di);
                 const f2 da0 = (2.f * mv) * (e0 * zp + e1 * zq + f2{HW[2 * p], HW[2 * p + 1]});
@@ -757,29 +761,34 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
                 f2 da1 = mv * (zz[p] + ed);
                 const f2 db1 = mv * (zz[p] - ed);
                 if (REAL) da1 += (mv * y0) * dr;
-                Bd[x * 32 + i] = f32x4{da0.x, db0.x, da1.x, db1.x};
-                Bd[(x + 1) * 32 + i] = f32x4{da0.y, db0.y, da1.y, db1.y};
+                Bd[pr * 32 + i] = f32x4{da0.x, da0.y, db0.x, db0.y};
+                Bd[PB + pr * 32 + i] = f32x4{da1.x, da1.y, db1.x, db1.y};
             }
+            Bd[ZV] = f32x4{0.f, 0.f, 0.f, 0.f};   // (the transposing buffers of the previous slab reached over it)
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_sched_barrier(0);
             {
-                // the 16 row reads are requested in two batches of eight and summed pairwise: two LDS round trips instead of
-                // the sixteen dependent ones the register-pressure heuristics of the compiler would leave
-                f32x4 rr[16];
-                f32x4 sv = G4[tsl + lane];
+                // the row reads are requested in batches and summed pairwise: two LDS round trips instead of the sixteen
+                // dependent ones the register-pressure heuristics of the compiler would leave
+                f32x4 ra[8], rb[8];
+                const f32x4 g0 = G4[tsl + lane];
 #pragma unroll
-                for (int x = 0; x < 16; ++x)   // row x, window lane - x (the zero vector when that is not a window of the slab)
-                    rr[x] = Bd[(unsigned)(lane - x) < 32u ? x * 31 + lane : 16 * 32];
+                for (int pr = 0; pr < 8; ++pr) {   // pair row pr, window lane - 2 pr (the zero vectors when that is not a window of the slab)
+                    const int idx = (unsigned)(lane - 2 * pr) < 32u ? pr * 30 + lane : ZV;
+                    ra[pr] = Bd[idx];
+                    rb[pr] = Bd[idx + PB];
+                }
+                f32x4 sa = ra[0], sb = rb[0];
 #pragma unroll
-                for (int x = 0; x < 16; x += 2) sv += rr[x] + rr[x + 1];
-                G4[tsl + lane] = sv;
-                __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);    // G4 + rows 0..7
+                for (int pr = 1; pr < 8; ++pr) { sa += ra[pr]; sb += rb[pr]; }
+                G4[tsl + lane] = g0 + f32x4{sa[0] + cx_shr1(sa[1]), sa[2] + cx_shr1(sa[3]), sb[0] + cx_shr1(sb[1]), sb[2] + cx_shr1(sb[3])};
+                __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);    // G4 + four pair rows
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {                         // a pair summed, the next pair requested
                     __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
