@@ -143,7 +143,10 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
     const unsigned ulane = lane;
     const float* cst = s_c + r * 4 * LEB;
     __syncthreads();
-    f32x4 Gr[NB][NB], Gi[NB][NB];
+    // dE/dH block (xb, jb) = sum over windows of (rho + i sigma)^T conj(X), a complex 16x16 accumulation, from three real products
+    // instead of four:  K1 = (rho + sigma)^T mu_a,  K2 = -rho^T (mu_a + mu_b),  K3 = sigma^T (mu_a - mu_b);  Re = K1 - K3,
+    // Im = K1 + K2 (combined once at the end: the sums are linear)
+    f32x4 K1[NB][NB], K2[NB][NB], K3[NB][NB];
     // vector gradients (d/dh1 Re, Im; d/d diag H Re, Im), accumulated in the TRANSPOSED layout the 16x16 MFMAs read (lane = (tap
     // lane & 15, window group lane >> 4)): one register per block and quantity instead of eight in the window-on-lane layout
     float vacc[NB][4];
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) { Gr[a][b][g] = 0.f; Gi[a][b][g] = 0.f; }
+            for (int g = 0; g < 4; ++g) { K1[a][b][g] = 0.f; K2[a][b][g] = 0.f; K3[a][b][g] = 0.f; }
 #pragma unroll
         for (int q = 0; q < 4; ++q) vacc[a][q] = 0.f;
     }
@@ -449,46 +452,56 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                 }
                 if (XT) HW = MFMA32(xbufB[xb], h == 0 ? al_e : be_e, HW);
                 BSTAMP(3);
-                // anti-diagonal sums (symbol = window + tap) of the gradients of means and variances: the four quantities of a
-                // (window, tap) pair travel as one 4-vector through the wave's buffer (16 tap rows of 32 windows and a zero vector
-                // that every out-of-range read is pointed at; the memory is the second transposing buffer's, used after it), the
-                // 16 row reads are requested in batches and the partial of this tap block is added to the slab's record.
+                // anti-diagonal sums (symbol = window + tap) of the gradients of means and variances through the wave's buffer
+                // (the memory is the second transposing buffer's, used after it): a (window, tap pair) writes its register pairs as
+                // they are - plane A holds (d mean_a, d mean_b), plane B (d var_a, d var_b), each as (even tap, odd tap) pairs, with a
+                // zero vector behind either plane that every out-of-range read is pointed at; lane m sums the eight pair rows at
+                // window m - even tap (reads requested in batches), the odd taps' sums, which belong to the next symbol, move up one
+                // lane at the end, and the partial of this tap block is added to the slab's record.
                 // The gradients of the 3rd moments and 4th cumulants do not need the residual: k_g2_cx has written them.
                 {
+                    constexpr int ZV = 8 * 32, PB = ZV + 1;
                     f32x4* Bd = reinterpret_cast<f32x4*>(Tv);
 #pragma unroll
                     for (int p = 0; p < 4; ++p) {
-                        const int xl = cx_kk(2 * p, h), x = 16 * xb + xl;
+                        const int xl = cx_kk(2 * p, h), x = 16 * xb + xl, pr = xl >> 1;
                         const f2 zp = zP[xb][p], zq = zQ[xb][p];
                         const f2 dr = ld2(cst + 2 * LEB + x), di = ld2(cst + 3 * LEB + x);
                         const f2 ed = 2.f * (e0 * dr + e1 * di), zzp = zp * zp + zq * zq;
                         const f2 d0 = (2.f * mv) * (e0 * zp + e1 * zq + f2{HW[2 * p], HW[2 * p + 1]});
                         const f2 d1 = (2.f * mv) * (e1 * zp - e0 * zq + f2{HW[2 * p + 8], HW[2 * p + 9]});
                         const f2 d2 = mv * (zzp + ed), d3 = mv * (zzp - ed);
-                        Bd[xl * 32 + i] = f32x4{d0.x, d1.x, d2.x, d3.x};
-                        Bd[(xl + 1) * 32 + i] = f32x4{d0.y, d1.y, d2.y, d3.y};
+                        Bd[pr * 32 + i] = f32x4{d0.x, d0.y, d1.x, d1.y};
+                        Bd[PB + pr * 32 + i] = f32x4{d2.x, d2.y, d3.x, d3.y};
                     }
-                    if (lane == 0) Bd[16 * 32] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (lane < 2) Bd[ZV + lane * PB] = f32x4{0.f, 0.f, 0.f, 0.f};
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_sched_barrier(0);
-                    f32x4 rr[16];
+                    f32x4 ra[8], rb[8];
 #pragma unroll
-                    for (int x = 0; x < 16; ++x)   // row x, window lane - x (the zero vector when that is not a window of the slab)
-                        rr[x] = Bd[(unsigned)(lane - x) < 32u ? x * 31 + lane : 16 * 32];
-                    f32x4 sv = rr[0] + rr[1];
+                    for (int pr = 0; pr < 8; ++pr) {
+                        const int idx = (unsigned)(lane - 2 * pr) < 32u ? pr * 30 + lane : ZV;
+                        ra[pr] = Bd[idx];
+                        rb[pr] = Bd[idx + PB];
+                    }
+                    f32x4 sa = ra[0], sb = rb[0];
 #pragma unroll
-                    for (int x = 2; x < 16; x += 2) sv += rr[x] + rr[x + 1];
+                    for (int pr = 1; pr < 8; ++pr) { sa += ra[pr]; sb += rb[pr]; }
+                    const float g0 = sa[0] + cx_shr1(sa[1]), g1 = sa[2] + cx_shr1(sa[3]);
+                    const float g2 = sb[0] + cx_shr1(sb[1]), g3 = sb[2] + cx_shr1(sb[3]);
                     __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {                         // a pair summed, the next pair requested
                         __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
                         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                     }
-                    __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     if (lane < 48) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) Pu[c * NSIG + 16 * xb + lane] += sv[c];
+                        Pu[0 * NSIG + 16 * xb + lane] += g0;
+                        Pu[1 * NSIG + 16 * xb + lane] += g1;
+                        Pu[2 * NSIG + 16 * xb + lane] += g2;
+                        Pu[3 * NSIG + 16 * xb + lane] += g3;
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -529,6 +542,7 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_sched_barrier(0);
                 {
                     const int xa = lane & 15, kq = lane >> 4;
                     float ar[8], as[8];
@@ -559,17 +573,26 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
                         for (int st = 0; st < 8; ++st) {
                             const int w = tsl + 4 * st + kq + 16 * jb + xa;
                             const float ma = s_mu[w], mb = s_mu[MS + w];
-                            Gr[xb][jb] = MFMA16(ar[st], ma, Gr[xb][jb]);
-                            Gr[xb][jb] = MFMA16(as[st], mb, Gr[xb][jb]);
-                            Gi[xb][jb] = MFMA16(as[st], ma, Gi[xb][jb]);
-                            Gi[xb][jb] = MFMA16(-ar[st], mb, Gi[xb][jb]);
+                            K1[xb][jb] = MFMA16(ar[st] + as[st], ma, K1[xb][jb]);
+                            K2[xb][jb] = MFMA16(-ar[st], ma + mb, K2[xb][jb]);
+                            K3[xb][jb] = MFMA16(as[st], ma - mb, K3[xb][jb]);
                             if (XT && xb == 0) {   // row e of dE/dH, once per slab: sum_w (rho, sigma)(w, e) mu(w + j)
                                 const f2 rs = ld2(Tb + (4 * st + kq) * TP + 32);   // (rho, sigma) of tap e at this window
                                 row[jb] += ma * rs + mb * f2{rs.y, -rs.x};
                             }
                         }
                     }
+                    // with one wave per SIMD every operand read waited for where it is used is idle time: the first reads are
+                    // requested before the chain starts, the others while it runs
+                    __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+#pragma unroll
+                    for (int k = 0; k < 8 * NB; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                    }
                 }
+                __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_wave_barrier();
                 BSTAMP(5);
             }
@@ -622,8 +645,8 @@ __global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restr
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int a = 16 * xb + 4 * (lane >> 4) + g, b = 16 * jb + (lane & 15);
-                        img[a * LEB + b] += Gr[xb][jb][g];
-                        img[(LEB + a) * LEB + b] += Gi[xb][jb][g];
+                        img[a * LEB + b] += K1[xb][jb][g] - K3[xb][jb][g];
+                        img[(LEB + a) * LEB + b] += K1[xb][jb][g] + K2[xb][jb][g];
                     }
                 {
                     float v0 = vacc[xb][0], v1 = vacc[xb][1], v2 = vacc[xb][2], v3 = vacc[xb][3];
