@@ -97,6 +97,59 @@ int rs_plan(const Lay& l, int64_t pack, RsOff* o) {
     return 1;
 }
 
+// Lane exchanges and wave sums on the vector pipe (DPP modifiers inside the rows of 16 lanes, half / quarter swaps across them):
+// a shuffle (`__shfl_xor`) is an LDS-pipeline instruction that the wave waits for, and this kernel runs one wave per SIMD.
+template <int CTRL>
+__device__ __forceinline__ float rs_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// the values of lanes ^ 16 (Q = 16) or ^ 32 (Q = 32): after the swap `a` holds, in both rows (halves) of a pair, the value of the even
+// one and `b` that of the odd one
+template <int Q>
+__device__ __forceinline__ void rs_swap_pair(float v, float& a, float& b) {
+    a = v; b = v;
+    if (Q == 16) asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    else asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+template <int OFF>
+__device__ __forceinline__ float rs_lane_xor(float v, int lane) {   // value of lane ^ OFF
+    if (OFF == 1) return rs_dpp<0xB1>(v);                       // quad_perm [1,0,3,2]
+    if (OFF == 2) return rs_dpp<0x4E>(v);                       // quad_perm [2,3,0,1]
+    if (OFF == 4) return rs_dpp<0x1B>(rs_dpp<0x141>(v));        // row_half_mirror (^ 7), then quad_perm [3,2,1,0] (^ 3)
+    if (OFF == 8) return rs_dpp<0x141>(rs_dpp<0x140>(v));       // row_mirror (^ 15), then row_half_mirror (^ 7)
+    float a, b;
+    rs_swap_pair<OFF>(v, a, b);
+    return (lane & OFF) ? a : b;
+}
+template <int OFF>
+__device__ __forceinline__ float rs_add_xor(float v) {      // v + (value of lane ^ OFF)
+    if (OFF < 16) return v + rs_lane_xor<OFF>(v, 0);
+    float a, b;
+    rs_swap_pair<OFF>(v, a, b);
+    return a + b;
+}
+__device__ __forceinline__ float rs_wave_sum(float v) {      // total over the 64 lanes, on every lane
+    v = rs_add_xor<1>(v); v = rs_add_xor<2>(v); v = rs_add_xor<4>(v); v = rs_add_xor<8>(v);
+    v = rs_add_xor<16>(v);
+    return rs_add_xor<32>(v);
+}
+__device__ __forceinline__ double rs_wave_sum(double v) {
+    auto step = [&](auto mover) {
+        const int lo = mover(__double2loint(v)), hi = mover(__double2hiint(v));
+        v += __hiloint2double(hi, lo);
+    };
+    auto ix = [](float f) { return __float_as_int(f); };
+    auto fx = [](int i) { return __int_as_float(i); };
+    step([&](int w) { return ix(rs_lane_xor<1>(fx(w), 0)); });
+    step([&](int w) { return ix(rs_lane_xor<2>(fx(w), 0)); });
+    step([&](int w) { return ix(rs_lane_xor<4>(fx(w), 0)); });
+    step([&](int w) { return ix(rs_lane_xor<8>(fx(w), 0)); });
+    const int lane = (int)(threadIdx.x & 63);
+    step([&](int w) { return ix(rs_lane_xor<16>(fx(w), lane)); });
+    step([&](int w) { return ix(rs_lane_xor<32>(fx(w), lane)); });
+    return v;
+}
+
 // Sum over the 64 lanes of N per-lane values each, N a power of two <= 64.  Returns in lane `ln` the total of element
 // e(ln) = sum over s < log2(N) of bit_s(ln) * (N >> (s + 1)); costs N - 1 exchanges instead of N * 6.
 template <int N>
@@ -109,12 +162,25 @@ __device__ __forceinline__ float rs_wave_reduce_transposed(float (&x)[N], int la
         for (int i = 0; i < n / 2; ++i) {
             const float lo = x[i], hi = x[i + n / 2];
             const float send = up ? lo : hi, keep = up ? hi : lo;
-            x[i] = keep + __shfl_xor(send, 1 << sft, 64);
+            float got;
+            switch (sft) {
+                case 0: got = rs_lane_xor<1>(send, lane); break;
+                case 1: got = rs_lane_xor<2>(send, lane); break;
+                case 2: got = rs_lane_xor<4>(send, lane); break;
+                case 3: got = rs_lane_xor<8>(send, lane); break;
+                case 4: got = rs_lane_xor<16>(send, lane); break;
+                default: got = rs_lane_xor<32>(send, lane); break;
+            }
+            x[i] = keep + got;
         }
     }
     float v = x[0];
-#pragma unroll
-    for (int off = N; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+    if (N <= 1) v = rs_add_xor<1>(v);
+    if (N <= 2) v = rs_add_xor<2>(v);
+    if (N <= 4) v = rs_add_xor<4>(v);
+    if (N <= 8) v = rs_add_xor<8>(v);
+    if (N <= 16) v = rs_add_xor<16>(v);
+    if (N <= 32) v = rs_add_xor<32>(v);
     return v;
 }
 
@@ -180,8 +246,7 @@ __device__ __forceinline__ int rs_transposed_index(int lane) {
 
 // total over the workgroup, returned to every thread; `red` holds RS_NW doubles
 __device__ __forceinline__ double rs_block_sum(double v, double* red, int tid) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    v = rs_wave_sum(v);
     __syncthreads();
     if ((tid & 63) == 0) red[tid >> 6] = v;
     __syncthreads();
@@ -370,7 +435,7 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
                 float part = 0.f;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) part = fmaf(acc[q] + k1w[q], xr[q], part);
-                part += __shfl_xor(part, 32, 64);
+                part = rs_add_xor<32>(part);
                 if (half == 0 && b < B) s_x[b] = part;
             }
         }
@@ -677,9 +742,7 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
             }
 #pragma unroll
             for (int k = 0; k < CB; ++k) {
-                float v = gs[k];
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                const float v = rs_wave_sum(gs[k]);
                 if (lane == 0 && k < C) s_misc[wv * MAX_C + k] = v;
             }
         }
@@ -769,7 +832,7 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
                 const int row = (q & 3) + 8 * (q >> 2) + 4 * half;
                 s_D[wv * 1024 + row * 32 + i] = acc[q];
             }
-            asum += __shfl_xor(asum, 32, 64);
+            asum = rs_add_xor<32>(asum);
             if (half == 0) s_D[RS_NW * 1024 + wv * 32 + i] = asum;
         }
         __syncthreads();
