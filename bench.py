@@ -170,6 +170,9 @@ def main():
                          "(complex 64-QAM, L=65, l1=l2=65, 2^23 symbols per GPU = 2^26 over 8, data generated on the device); "
                          "sweep: 1024 independent real PAM-4 models, L=15")
     args = ap.parse_args()
+    if os.environ.get("V2VAE_BENCH_WATCHDOG"):   # diagnostic: every thread's Python stack after that many seconds, then exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["V2VAE_BENCH_WATCHDOG"]), exit=True)
     if args.workload == "sweep":
         return sweep_main(args)
     if args.workload == "cfg4":

@@ -1368,7 +1368,8 @@ struct SumSet {
     const float* part;
     float* stage;
     float* tot;
-    int rec, nrec, per, chunks;
+    float* copy_to;   // the totals also go here (set or added, `copy_acc`) by the stage that forms them: no copy launch
+    int rec, nrec, per, chunks, copy_acc;
 };
 struct SumSets {
     SumSet s[3];
@@ -1378,18 +1379,25 @@ struct SumSets {
 __global__ __launch_bounds__(NT) void k_sum_multi(SumSets ss, int second) {
     const SumSet q = ss.s[blockIdx.z];
     const GridCtx gc{(int)blockIdx.x, (int)gridDim.x};
+    bool final_stage = false;
     if (!second) {
         if ((int)blockIdx.y >= q.chunks) return;
         d_sum_records(gc, (int)blockIdx.y, q.part, q.rec, q.nrec, q.per, q.chunks > 1 ? q.stage : q.tot);
+        final_stage = q.chunks == 1;
     } else if (q.chunks > 1) {
         d_sum_records(gc, 0, q.stage, q.rec, q.chunks, q.chunks, q.tot);
+        final_stage = true;
     }
+    // every thread re-reads only the totals it has just written itself (same index mapping as d_sum_records)
+    if (final_stage && q.copy_to)
+        for (int i = gc.bid * NT + threadIdx.x; i < q.rec; i += gc.nb * NT) q.copy_to[i] = q.copy_acc ? q.copy_to[i] + q.tot[i] : q.tot[i];
 }
 
-static void sum_sets_add(SumSets& ss, const float* part, int rec, int nrec, float* stage, float* tot) {
+static void sum_sets_add(SumSets& ss, const float* part, int rec, int nrec, float* stage, float* tot, float* copy_to = nullptr,
+                         int copy_acc = 0) {
     if (rec <= 0) return;
     SumSet& q = ss.s[ss.n++];
-    q.part = part; q.stage = stage; q.tot = tot; q.rec = rec; q.nrec = nrec;
+    q.part = part; q.stage = stage; q.tot = tot; q.rec = rec; q.nrec = nrec; q.copy_to = copy_to; q.copy_acc = copy_acc;
     if (nrec <= SUM_CHUNKS) { q.per = nrec; q.chunks = 1; }
     else { q.per = (nrec + SUM_CHUNKS - 1) / SUM_CHUNKS; q.chunks = (nrec + q.per - 1) / q.per; }
 }
@@ -1548,10 +1556,6 @@ __global__ __launch_bounds__(NT) void k_chain_equaliser(Lay l, const float* __re
 __device__ __forceinline__ void d_copy(const GridCtx gc, const float* __restrict__ src, float* __restrict__ dst, int n,
                                        int accumulate = 0) {
     for (int i = gc.bid * NT + threadIdx.x; i < n; i += gc.nb * NT) dst[i] = accumulate ? dst[i] + src[i] : src[i];
-}
-
-__global__ __launch_bounds__(NT) void k_copy(const float* __restrict__ src, float* __restrict__ dst, int n, int accumulate) {
-    d_copy(GridCtx{(int)blockIdx.x, (int)gridDim.x}, src, dst, n, accumulate);
 }
 
 __device__ __forceinline__ void d_adam(const GridCtx gc, int64_t n, float* __restrict__ p, const float* __restrict__ g,
@@ -1924,7 +1928,8 @@ int v2vae_finish_grads(const v2vae_problem* p, void* ws, const double* scal, con
     if ((which & 1) && l.use_cx) sum_sets_add(ss, w + l.o_part_cx, l.S * CX_REC, l.nblk_cx, stage, w + l.o_tot_cx);
     else if ((which & 1) && l.use_cxb) sum_sets_add(ss, w + l.o_part_cxb, l.S * l.cxb_rec, l.nblk_cxb, stage, w + l.o_tot_cxb);
     else if (which & 1) sum_sets_add(ss, w + l.o_part_elbo, l.rec_elbo, l.nblk_elbo, stage, w + l.o_tot_elbo);
-    if (which & 2) sum_sets_add(ss, w + l.o_part_sym, l.rec_sym, l.nblk_sym, stage + l.sumstage_stride, w + l.o_tot_sym);
+    if (which & 2) sum_sets_add(ss, w + l.o_part_sym, l.rec_sym, l.nblk_sym, stage + l.sumstage_stride, w + l.o_tot_sym, g_scaling,
+                                (which & 8) ? 1 : 0);
     if ((which & 4) && l.eqb16) sum_sets_add(ss, w + l.o_part_eqcx, l.eqb16_rec, l.nblk_eq, stage + 2 * l.sumstage_stride, w + l.o_tot_eqcx);
     else if ((which & 4) && l.use_eqcxb) sum_sets_add(ss, w + l.o_part_eqcxb, l.eqcxb_rec, l.nblk_eq, stage + 2 * l.sumstage_stride, w + l.o_tot_eqcxb);
     else if (which & 4) sum_sets_add(ss, w + l.o_part_eq, l.rec_eq, l.nblk_eq, stage + 2 * l.sumstage_stride, w + l.o_tot_eq);
@@ -1937,9 +1942,6 @@ int v2vae_finish_grads(const v2vae_problem* p, void* ws, const double* scal, con
         const int n = l.ns * l.L + l.ns * l.L * l.L;
         hipLaunchKernelGGL(k_chain_channel, dim3((n + NT - 1) / NT), dim3(NT), 0, st, l, (const float*)w, scal, grad_scale, g_h1, g_h2);
     }
-    if ((which & 2) && g_scaling)
-        hipLaunchKernelGGL(k_copy, dim3((l.rec_sym + NT - 1) / NT), dim3(NT), 0, st, (const float*)(w + l.o_tot_sym), g_scaling, l.rec_sym,
-                           (which & 8) ? 1 : 0);
     if ((which & 4) && l.eqb16) {
         launch_chain_equaliser_cx(l, w, g_k1, g_k2, st);
     } else if ((which & 4) && l.use_eqcxb) {
