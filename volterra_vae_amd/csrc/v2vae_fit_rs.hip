@@ -623,21 +623,36 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
                 const int ml = tid + sub * RS_NT;
                 if (ml < o.TS && s0 + ml < s1) {
                     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                    // four taps at a time: their sixteen reads are requested together (with one wave per SIMD a read waited for
+                    // where it is used is idle time; the register budget does not allow all eight taps at once)
 #pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) {
-                        const bool act = kk < LE;
-                        const int slot = act ? ml + kmax - kk : 0;
-                        const float d0 = s_D[(0 * 8 + kk) * RS_SLOTS + slot], d1 = s_D[(1 * 8 + kk) * RS_SLOTS + slot];
-                        const float d2 = s_D[(2 * 8 + kk) * RS_SLOTS + slot], vs = s_vl[slot];
-                        const float dk = s_d[r * 8 + kk];
-                        a0 += act ? d0 : 0.f;
-                        a1 += act ? d1 : 0.f;
-                        a2 += act ? d2 : 0.f;
-                        a3 = fmaf(act ? vs : 0.f, dk * dk, a3);
+                    for (int k4 = 0; k4 < 8; k4 += 4) {
+                        float d0[4], d1[4], d2[4], vs[4], dk[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int kk = k4 + u;
+                            const int slot = kk < LE ? ml + kmax - kk : 0;
+                            d0[u] = s_D[(0 * 8 + kk) * RS_SLOTS + slot]; d1[u] = s_D[(1 * 8 + kk) * RS_SLOTS + slot];
+                            d2[u] = s_D[(2 * 8 + kk) * RS_SLOTS + slot]; vs[u] = s_vl[slot];
+                            dk[u] = s_d[r * 8 + kk];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const bool act = k4 + u < LE;
+                            a0 += act ? d0[u] : 0.f;
+                            a1 += act ? d1[u] : 0.f;
+                            a2 += act ? d2[u] : 0.f;
+                            a3 = fmaf(act ? vs[u] : 0.f, dk[u] * dk[u], a3);
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x100, 20, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);
                     }
                     float* gp = s_gm + s0 + ml;
                     if (r == 0) { gp[0] = a0; gp[GP] = a1; gp[2 * GP] = a2; gp[3 * GP] = a3; }
-                    else { gp[0] += a0; gp[GP] += a1; gp[2 * GP] += a2; gp[3 * GP] += a3; }
+                    else {   // the four reads before the first write: one LDS round trip instead of four (one wave per SIMD)
+                        const float o0 = gp[0], o1 = gp[GP], o2 = gp[2 * GP], o3 = gp[3 * GP];
+                        gp[0] = o0 + a0; gp[GP] = o1 + a1; gp[2 * GP] = o2 + a2; gp[3 * GP] = o3 + a3;
+                    }
                 }
                 }
                 __syncthreads();
