@@ -22,21 +22,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Sample tile from global sample g0 on, the two streams INTERLEAVED ([tile_len][2]: one 8-byte LDS read gives both parts of
 // a sample).  A tile that lies inside both the global sequence and the local sample block (all but the first and last few) is
 // copied without per-element checks; indices stay 32-bit inside the tile.
+// REAL: the real model (one stream): the quadrature part of every sample is zero.
+template <bool REAL>
 __device__ __forceinline__ void eqcx_load_tile(const Lay& l, const float* __restrict__ y, int64_t g0, float* tile) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     const int tl = l.tile_len;
     const int64_t loc0 = g0 - l.y_lo;
     const bool inside = g0 >= 0 && g0 + tl <= l.n_glob && loc0 >= 0 && loc0 + tl <= l.y_len;   // uniform
     const float* __restrict__ sa = y + loc0;
-    const float* __restrict__ sb = y + l.y_stride + loc0;
+    const float* __restrict__ sb = REAL ? sa : y + l.y_stride + loc0;
     f2* dst = reinterpret_cast<f2*>(tile);
     if (inside) {
-        for (int i = threadIdx.x; i < tl; i += NT) dst[i] = f2{sa[i], sb[i]};
+        for (int i = threadIdx.x; i < tl; i += NT) dst[i] = f2{sa[i], REAL ? 0.f : sb[i]};
     } else {
         for (int i = threadIdx.x; i < tl; i += NT) {
             const int64_t g = g0 + i, loc = loc0 + i;
             const bool in = g >= 0 && g < l.n_glob && loc >= 0 && loc < l.y_len;
-            dst[i] = in ? f2{sa[i], sb[i]} : f2{0.f, 0.f};
+            dst[i] = in ? f2{sa[i], REAL ? 0.f : sb[i]} : f2{0.f, 0.f};
         }
     }
 }
@@ -45,14 +47,16 @@ __device__ __forceinline__ void eqcx_load_tile(const Lay& l, const float* __rest
 // SS = samples per symbol when it is 1 or 2 (the sample offsets of the unrolled symbol loop are then instruction immediates),
 // 0 = read from the layout.
 // LDS: sample tile [tile_len][2] | per-symbol gradient combinations, 4-vectors [EQ_TB] and a plane [EQ_TB] | constant (1, 0) samples [64 S][2].
-template <int NB16, int SS>
+// REAL: the real model through the same kernel: Yb = 0 and g1 = 0, so rho = g0 Ya, sigma = 0 and the gradient plane dK = sum rho^T Ya
+// is the first of the three products alone (one MFMA per block and k-step instead of three; the second plane of the record stays zero).
+template <int NB16, int SS, bool REAL>
 __global__ __launch_bounds__(NT, NB16 <= 3 ? 4 : 2) void k_eq_bwd_cx(Lay l, const float* __restrict__ y, const float* __restrict__ gx,
                                                                   float* __restrict__ ws) {
     constexpr int NBLK = NB16 * (NB16 + 1) / 2, LD = 16 * NB16;
     extern __shared__ __align__(16) float sm[];
     const int S = SS ? SS : l.S;
     float* tile = sm;
-    const int ntl = (l.ns * l.tile_len + 3) & ~3;
+    const int ntl = (2 * l.tile_len + 3) & ~3;   // interleaved (Ya, Yb) pairs, also for the real model
     f32x4* g4 = reinterpret_cast<f32x4*>(sm + ntl);   // (g0 + g1, g1, g1 - g0, -g0) per symbol of the tile
     float* ng1 = sm + ntl + 4 * EQ_TB;                 // -g1
     const int o_ones = ntl + 5 * EQ_TB;   // (1, 0) pairs
@@ -90,10 +94,10 @@ __global__ __launch_bounds__(NT, NB16 <= 3 ? 4 : 2) void k_eq_bwd_cx(Lay l, cons
         const int64_t rem = l.own_lo + l.own_cnt - b0;
         const int nbs = rem < EQ_TB ? (int)rem : EQ_TB;
         __syncthreads();
-        eqcx_load_tile(l, y, b0 * l.S - l.hl, tile);
+        eqcx_load_tile<REAL>(l, y, b0 * l.S - l.hl, tile);
         {   // EQ_TB == NT: one symbol per thread
             const float g0 = tid < nbs ? gx[b0 + tid - l.sym_lo] : 0.f;
-            const float g1 = tid < nbs ? gx[l.sym_cnt + (b0 + tid - l.sym_lo)] : 0.f;
+            const float g1 = (!REAL && tid < nbs) ? gx[l.sym_cnt + (b0 + tid - l.sym_lo)] : 0.f;
             g4[tid] = f32x4{g0 + g1, g1, g1 - g0, -g0};
             ng1[tid] = -g1;
         }
@@ -108,11 +112,12 @@ __global__ __launch_bounds__(NT, NB16 <= 3 ? 4 : 2) void k_eq_bwd_cx(Lay l, cons
             for (int ib = 0; ib < NB16; ++ib) {
                 const f2 x = pa[ib][4 * s * S];
                 const float xa = x.x, xb = x.y;
+                ca[ib] = xa;
+                if (REAL) { rs[ib] = gg.x * xa; continue; }
                 const f2 t = f2{gg.x, gg.y} * xa + f2{gg.z, gg.w} * xb;   // (rho + sigma, sigma = g1 Ya - g0 Yb)
                 rs[ib] = t.x;
                 sig[ib] = t.y;
                 nrho[ib] = fmaf(gg.w, xa, n1 * xb);  // -(g0 Ya + g1 Yb)
-                ca[ib] = xa;
                 cs[ib] = xa + xb;
                 cd[ib] = xa - xb;
             }
@@ -122,8 +127,10 @@ __global__ __launch_bounds__(NT, NB16 <= 3 ? 4 : 2) void k_eq_bwd_cx(Lay l, cons
                 for (int jb = ib; jb < NB16; ++jb) {
                     const int q = ib * NB16 - ib * (ib - 1) / 2 + (jb - ib);
                     A[q] = MFMA16(rs[ib], ca[jb], A[q]);
-                    B[q] = MFMA16(nrho[ib], cs[jb], B[q]);
-                    C[q] = MFMA16(sig[ib], cd[jb], C[q]);
+                    if (!REAL) {
+                        B[q] = MFMA16(nrho[ib], cs[jb], B[q]);
+                        C[q] = MFMA16(sig[ib], cd[jb], C[q]);
+                    }
                 }
         }
     }
@@ -142,8 +149,8 @@ __global__ __launch_bounds__(NT, NB16 <= 3 ? 4 : 2) void k_eq_bwd_cx(Lay l, cons
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int e = (16 * ib + 4 * kq + g) * LD + 16 * jb + i16;
-                        img[e] += A[q][g] - C[q][g];
-                        img[LD * LD + e] += A[q][g] + B[q][g];
+                        img[e] += REAL ? A[q][g] : A[q][g] - C[q][g];
+                        if (!REAL) img[LD * LD + e] += A[q][g] + B[q][g];
                     }
                 }
         }
@@ -157,7 +164,7 @@ __global__ __launch_bounds__(NT) void k_chain_equaliser_cx(Lay l, const float* _
                                                            float* __restrict__ g_k2) {
     const float* T = ws + l.o_tot_eqcx;
     const int l1 = l.l1, l2 = l.l2, LD = 16 * l.eqb16, PL = LD * LD;
-    const int n1 = 2 * l1, n2 = 2 * l2 * l2;
+    const int n1 = l.ns * l1, n2 = l.ns * l2 * l2;   // two parameter planes (Re, Im); the real model has one
     auto GK = [&](int p, int a, int b) {  // dE/dK (effective symmetric kernel), plane p: a lower block is its partner transposed
         return (a >> 4) > (b >> 4) ? T[p * PL + b * LD + a] : T[p * PL + a * LD + b];
     };
@@ -179,12 +186,17 @@ __global__ __launch_bounds__(NT) void k_chain_equaliser_cx(Lay l, const float* _
 
 int launch_eq_bwd_cx(const Lay& l, const float* y, const float* gx, float* ws, hipStream_t st) {
     const int lds = l.lds_eqb16;
-#define V2VAE_LAUNCH_EQB16_S(NB, SS)                                                                                             \
+#define V2VAE_LAUNCH_EQB16_R(NB, SS, RR)                                                                                         \
     do {                                                                                                                         \
-        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k_eq_bwd_cx<NB, SS>),                            \
+        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k_eq_bwd_cx<NB, SS, RR>),                        \
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)               \
             return V2VAE_ELAUNCH;                                                                                                \
-        hipLaunchKernelGGL((k_eq_bwd_cx<NB, SS>), dim3(l.nblk_eq), dim3(NT), lds, st, l, y, gx, ws);                              \
+        hipLaunchKernelGGL((k_eq_bwd_cx<NB, SS, RR>), dim3(l.nblk_eq), dim3(NT), lds, st, l, y, gx, ws);                          \
+    } while (0)
+#define V2VAE_LAUNCH_EQB16_S(NB, SS)                     \
+    do {                                                 \
+        if (l.ns == 1) V2VAE_LAUNCH_EQB16_R(NB, SS, true); \
+        else V2VAE_LAUNCH_EQB16_R(NB, SS, false);        \
     } while (0)
 #define V2VAE_LAUNCH_EQB16(NB)                       \
     do {                                             \
@@ -202,11 +214,12 @@ int launch_eq_bwd_cx(const Lay& l, const float* y, const float* gx, float* ws, h
     }
 #undef V2VAE_LAUNCH_EQB16
 #undef V2VAE_LAUNCH_EQB16_S
+#undef V2VAE_LAUNCH_EQB16_R
     return V2VAE_OK;
 }
 
 void launch_chain_equaliser_cx(const Lay& l, float* ws, float* g_k1, float* g_k2, hipStream_t st) {
-    const int n = 2 * l.l1 + 2 * l.l2 * l.l2;
+    const int n = l.ns * (l.l1 + l.l2 * l.l2);
     hipLaunchKernelGGL(k_chain_equaliser_cx, dim3((n + NT - 1) / NT), dim3(NT), 0, st, l, (const float*)ws, g_k1, g_k2);
 }
 

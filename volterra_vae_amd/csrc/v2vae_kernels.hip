@@ -199,10 +199,14 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     // persistent backward kernels: exactly the workgroups that are resident at once (register use: 4 per CU for the
     // single-block kernel, 2 with two lag blocks, 1 with three), so that no partly filled second round trails the first
     l.eqb16 = (l.use_eqcx || (l.use_eqcxb && l.l2 <= 79)) ? (l.l2 + 1 + 15) / 16 : 0;
+    // the real model's equaliser BACKWARD runs the same kernel on a zero quadrature stream wherever its ELBO does (large batches;
+    // any batch on request); the forward keeps the generic kernel, whose sums in double carry the remainder the demapper needs
+    if (l.cx_real && l.l2 >= 1 && l.l2 <= 79 && (l.l1 & 1) && l.l1 <= l.l2 && l.pad1 == l.l1 / 2)
+        l.eqb16 = (l.l2 + 1 + 15) / 16;
     l.eqb16_rec = 2 * (16 * l.eqb16) * (16 * l.eqb16);
     {
-        // sample tile, per-symbol gradient combinations (5 per symbol), constant ones / zeros (64 S each); afterwards the record
-        const int64_t a = (((int64_t)l.ns * l.tile_len + 3) & ~(int64_t)3) + 5 * EQ_TB + 128 * l.S, b = l.eqb16_rec;
+        // sample tile (interleaved pairs), per-symbol gradient combinations (5 per symbol), constant ones / zeros (64 S each); afterwards the record
+        const int64_t a = (((int64_t)2 * l.tile_len + 3) & ~(int64_t)3) + 5 * EQ_TB + 128 * l.S, b = l.eqb16_rec;
         l.lds_eqb16 = (int)((a > b ? a : b) * 4);
     }
     if (l.eqb16) l.nblk_eq = l.eqb16 <= 3 ? (l.ntile_eq < 1024 ? l.ntile_eq : 1024) : (l.ntile_eq < 512 ? l.ntile_eq : 512);
