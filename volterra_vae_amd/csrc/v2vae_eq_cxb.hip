@@ -434,6 +434,144 @@ __global__ __launch_bounds__(NT, T <= 25 ? 4 : 3) void k_eq_fwd_sym(Lay l, const
     }
 }
 
+// The REAL model's forward in the same symmetric form, with every sum in double (v_fma_f64 issues at the rate of an unpacked f32
+// FMA on this part): xhat = sum_a y_a (k1w_a + sum_{b >= a} K'_ab y_b) - T (T + 1) / 2 + T multiply-adds per symbol against the
+// T^2 of the generic kernel, samples in registers as doubles, table entries (doubles, same row-interleaved stream as above) by
+// scalar loads, eight per load.  The result leaves as a float plus its float remainder (planes o_xhi / o_xlo), exactly like the
+// generic real forward: the soft demapper amplifies an error of xhat by 2 |xhat - a| / noise variance.
+typedef double eq_d8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(NT) void k_prep_eqsymr(Lay l, const float* __restrict__ k1, const float* __restrict__ k2, float* __restrict__ ws) {
+    const int T = l.eqsym_t, ne = T * (T + 1) / 2 + T, l1 = l.l1, l2 = l.l2;
+    double* tab = reinterpret_cast<double*>(ws + l.o_eqsym);
+    for (int idx = blockIdx.x * NT + threadIdx.x; idx < ne + 8; idx += gridDim.x * NT) {
+        double v = 0.0;
+        if (idx < ne) {
+            int a = 0, rem = idx;
+            while (rem >= T - a + 1) { rem -= T - a + 1; ++a; }
+            if (rem == 0) {
+                const int jj = l.pad1 + l.p2 - a;  // first-order tap that multiplies lag a
+                if (a < l2 && jj >= 0 && jj < l1) v = (double)k1[jj];
+            } else {
+                const int b = a + rem - 1;
+                // the symmetrised entry as the generic kernel's table holds it (a float sum), doubled off the diagonal
+                if (b < l2) v = (a == b ? 1.0 : 2.0) * (double)(k2[a * l2 + b] + k2[b * l2 + a]);
+            }
+        }
+        tab[idx] = v;
+    }
+}
+
+template <int T>
+__global__ __launch_bounds__(NT, 2) void k_eq_fwd_symr(Lay l, const float* __restrict__ y, float* __restrict__ ws, float* __restrict__ xhat) {
+    extern __shared__ float sm[];
+    float* tile = sm;
+    constexpr int NSY = 2, TB = NSY * EQ_TB;
+    const int tid = threadIdx.x;
+    const float* tab0 = ws + l.o_eqsym;
+    const int64_t sym_hi = l.sym_lo + l.sym_cnt;
+    const int64_t ntile = (l.sym_cnt + TB - 1) / TB;
+    const int xh = T - l.l2;   // extra left halo: table entries of lags from l2 on are zero, their samples only have to be finite
+    const int tlen = l.tile_len + xh + (NSY - 1) * EQ_TB * l.S;
+    for (int64_t t = blockIdx.x; t < ntile; t += gridDim.x) {
+        const int64_t b0 = l.sym_lo + t * TB;
+        // (opaque per tile, constant address space: see k_eq_fwd_sym)
+        typedef const double __attribute__((address_space(4))) * ctab_p;
+        const float* tab_generic = tab0;
+        asm volatile("" : "+s"(tab_generic));
+        const ctab_p tab = (ctab_p)tab_generic;
+        __syncthreads();
+        {
+            const int64_t g0 = b0 * l.S - l.hl - xh, loc0 = g0 - l.y_lo;
+            const bool inside = g0 >= 0 && g0 + tlen <= l.n_glob && loc0 >= 0 && loc0 + tlen <= l.y_len;   // uniform
+            const float* __restrict__ sa = y + loc0;
+            if (inside) {
+                for (int i = tid; i < tlen; i += NT) tile[i] = sa[i];
+            } else {
+                for (int i = tid; i < tlen; i += NT) {
+                    const int64_t g = g0 + i, loc = loc0 + i;
+                    tile[i] = (g >= 0 && g < l.n_glob && loc >= 0 && loc < l.y_len) ? sa[i] : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        double yv[NSY][T];
+#pragma unroll
+        for (int n = 0; n < NSY; ++n) {
+            const int base = (tid + n * EQ_TB) * l.S + l.hl + xh + l.p2;
+#pragma unroll
+            for (int x = 0; x < T; ++x) yv[n][x] = (double)tile[base - x];
+        }
+        double out[NSY], u[NSY];
+#pragma unroll
+        for (int n = 0; n < NSY; ++n) { out[n] = 0.0; u[n] = 0.0; }
+        // Two alternating register sets of eight entries.  Scalar loads return out of order, so the only wait there is waits for
+        // ALL of them: the load of the next eight entries must be issued AFTER the wait for the current eight, or that wait would
+        // cover it too.  Left to the compiler the loads (invariant, constant address space) are all hoisted to the top of the tile
+        // and hundreds of scalar registers are spilled; so load and wait are written out here - the wait names the register set
+        // as in / out operand (its consumers stay behind it), the compiler, which does not know of a load in flight, adds no
+        // wait of its own, and a scheduling fence at every boundary keeps the multiply-adds of a set between its wait and the
+        // load that overwrites it.
+        constexpr int NE = T * (T + 1) / 2 + T, NCH = (NE + 7) / 8;
+        eq_d8 kb[2];
+        auto issue = [&](int c) { asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(kb[c & 1]) : "s"(tab), "s"(c * 64)); };
+        auto arrive = [&](int c) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(kb[c & 1]));
+            if (c + 1 < NCH) issue(c + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // the samples have arrived (a wait the compiler knows of: it adds none behind the loads)
+        issue(0);
+#pragma unroll
+        for (int a = 0; a < T; ++a) {
+            const int off = a * (T + 1) - a * (a - 1) / 2;   // flat index of the first-order weight that opens row a
+            if ((off & 7) == 0) arrive(off >> 3);
+#pragma unroll
+            for (int n = 0; n < NSY; ++n) u[n] = kb[(off >> 3) & 1][off & 7];
+#pragma unroll
+            for (int b = a; b < T; ++b) {
+                const int idx = off + 1 + (b - a);
+                if ((idx & 7) == 0) arrive(idx >> 3);
+#pragma unroll
+                for (int n = 0; n < NSY; ++n)   // (volatile: keeps its place between the hand-placed loads and waits)
+                    asm volatile("v_fmac_f64_e32 %0, %1, %2" : "+v"(u[n]) : "s"(kb[(idx >> 3) & 1][idx & 7]), "v"(yv[n][b]));
+            }
+#pragma unroll
+            for (int n = 0; n < NSY; ++n) out[n] = fma(u[n], yv[n][a], out[n]);
+        }
+#pragma unroll
+        for (int n = 0; n < NSY; ++n) {
+            const int64_t b = b0 + tid + n * EQ_TB;
+            if (b < sym_hi) {
+                const float hi = (float)out[n];
+                xhat[b - l.sym_lo] = hi;
+                ws[l.o_xhi + (b - l.sym_lo)] = hi;
+                ws[l.o_xlo + (b - l.sym_lo)] = (float)(out[n] - (double)hi);
+            }
+        }
+    }
+}
+
+int launch_prep_eqsymr(const Lay& l, const float* k1, const float* k2, float* ws, hipStream_t st) {
+    hipLaunchKernelGGL(k_prep_eqsymr, dim3(2), dim3(NT), 0, st, l, k1, k2, ws);
+    return V2VAE_OK;
+}
+
+int launch_eq_fwd_symr(const Lay& l, const float* y, float* ws, float* xhat, hipStream_t st) {
+    const int nt = (int)((l.sym_cnt + 2 * EQ_TB - 1) / (2 * EQ_TB));
+    const int nb = nt < 2 * CX_BLOCKS ? nt : 2 * CX_BLOCKS;   // resident workgroups: two per CU (launch bounds)
+    const int lds = (l.tile_len + (l.eqsym_t - l.l2) + EQ_TB * l.S) * 4;
+    switch (l.eqsym_t) {
+        case 9: hipLaunchKernelGGL(k_eq_fwd_symr<9>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat); break;
+        case 17: hipLaunchKernelGGL(k_eq_fwd_symr<17>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat); break;
+        case 25: hipLaunchKernelGGL(k_eq_fwd_symr<25>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat); break;
+        case 31: hipLaunchKernelGGL(k_eq_fwd_symr<31>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat); break;
+        default: return V2VAE_ESIZE;
+    }
+    return V2VAE_OK;
+}
+
 template <typename K>
 static int eqcxb_allow_lds(K kernel, int bytes) {
     if (bytes <= 64 * 1024) return V2VAE_OK;

@@ -260,6 +260,9 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     // symmetric-form forward on the vector pipe: half the multiply-adds of the matrix product and no padding of the lag count
     l.eqsym_t = l.use_eqcx ? (l.l2 <= 9 ? 9 : l.l2 <= 17 ? 17 : l.l2 <= 25 ? 25 : 31)
                            : (l.use_eqcxb && l.l2 <= 65) ? (l.l2 <= 47 ? 47 : 65) : 0;
+    // real model on the matrix-core path (see eqb16 above): forward in symmetric form, sums in double, up to 31 lags
+    l.eqsymr = (l.cx_real && l.eqb16 && l.l2 <= 31) ? 1 : 0;
+    if (l.eqsymr) l.eqsym_t = l.l2 <= 9 ? 9 : l.l2 <= 17 ? 17 : l.l2 <= 25 ? 25 : 31;
     l.o_eqsym = take(l.eqsym_t ? l.eqsym_t * (l.eqsym_t + 1) + 2 * l.eqsym_t + 16 : 0);
     l.o_part_eqcxb = take((l.use_eqcxb && !l.eqb16) ? (int64_t)l.nblk_eq * l.eqcxb_rec : 0);
     l.o_tot_eqcxb = take((l.use_eqcxb && !l.eqb16) ? l.eqcxb_rec : 0);
@@ -1759,6 +1762,7 @@ int v2vae_prep_tables(const v2vae_problem* p, const float* h1, const float* h2, 
     if (!ws || (!h1 && !k1) || (h1 && !h2) || (k1 && l.l2 > 0 && !k2)) return V2VAE_EINVAL;
     hipLaunchKernelGGL(k_prep_tables, dim3(16), dim3(NT), 0, (hipStream_t)stream, l, h1, h2, k1, k2, (float*)ws);
     if (k1 && l.eqcxb_fwd) launch_prep_eqcxb(l, k1, k2, (float*)ws, (hipStream_t)stream);
+    if (k1 && l.eqsymr) launch_prep_eqsymr(l, k1, k2, (float*)ws, (hipStream_t)stream);
     if (h1 && l.use_cxb) launch_prep_cxb(l, h1, h2, (float*)ws, (hipStream_t)stream);
     return launch_status();
 }
@@ -1770,6 +1774,10 @@ int v2vae_eq_fwd(const v2vae_problem* p, const float* y, void* ws, float* xhat, 
     if (!y || !ws || !xhat) return V2VAE_EINVAL;
     if (l.eqcxb_fwd) {
         rc = launch_eq_fwd_cxb(l, y, (const float*)ws, xhat, (hipStream_t)stream);
+        return rc ? rc : launch_status();
+    }
+    if (l.eqsymr) {
+        rc = launch_eq_fwd_symr(l, y, (float*)ws, xhat, (hipStream_t)stream);
         return rc ? rc : launch_status();
     }
     rc = allow_lds(k_eq_fwd, l.lds_eq);

@@ -94,6 +94,7 @@ struct Lay {
     // symmetric-form forward equaliser (complex, l2 <= 31): table of the upper-triangular kernel pairs, (Re, Im) each, off-diagonal
     // entries doubled, rows a = 0 .. eqsym_t - 1 of columns b = a .. eqsym_t - 1, then the first-order kernel per lag (Re, Im)
     int eqsym_t;             // compile-time lag count of the kernel instance that serves l2 (0: not used)
+    int eqsymr;              // 1: the real model's forward in symmetric form with sums in double (k_eq_fwd_symr); the table then holds doubles
     int64_t o_eqsym;
     int64_t o_sumstage;      // 3 x [SUM_CHUNKS][largest record] staging of the two-stage record sums (one per record set)
     int64_t sumstage_stride; // floats between the three staging areas
@@ -115,6 +116,8 @@ V2VAE_HD inline int rec_elbo_phase(const Lay& l) { return l.ns * l.LTp * l.LTp +
 int make_layout(const v2vae_problem* p, Lay* out);
 int launch_prep_eqcxb(const Lay& l, const float* k1, const float* k2, float* ws, hipStream_t st);
 int launch_eq_fwd_cxb(const Lay& l, const float* y, const float* ws, float* xhat, hipStream_t st);
+int launch_prep_eqsymr(const Lay& l, const float* k1, const float* k2, float* ws, hipStream_t st);
+int launch_eq_fwd_symr(const Lay& l, const float* y, float* ws, float* xhat, hipStream_t st);
 int launch_eq_bwd_cxb(const Lay& l, const float* y, const float* gx, float* ws, hipStream_t st);
 void launch_chain_equaliser_cxb(const Lay& l, float* ws, float* g_k1, float* g_k2, hipStream_t st);
 
