@@ -17,7 +17,7 @@ import os, sys, numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, os.environ["V2VAE_ROOT"])
 from volterra_vae_amd.distributed import ShardedTrainer, shard_ranges
 from volterra_vae_amd.ops import Plan
-from volterra_vae_amd.synth import nonlinear_isi_range, qam_constellation
+from volterra_vae_amd.synth import nonlinear_isi_range, pam_constellation, qam_constellation
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dev = torch.device("cuda", 0)
 backend = os.environ.get("V2VAE_BACKEND", "gloo")
@@ -28,20 +28,22 @@ else:
     dist.init_process_group("gloo", rank=rank, world_size=world)
 L, S, l1, l2, M, B = [int(v) for v in os.environ["V2VAE_SHAPE"].split(",")]
 n_glob = B * S
+real = bool(os.environ.get("V2VAE_REAL"))   # the real (PAM) model: one stream
+ns = 1 if real else 2
 sr = shard_ranges(rank, world, n_glob, S, L, l1, l1 // 2, l2)
-plan = Plan(ns=2, sps=S, l1=l1, pad1=l1 // 2, l2=l2, L=L, C_levels=M, n_glob=n_glob, device=dev, y_lo=sr.y_lo, y_len=sr.y_len,
+plan = Plan(ns=ns, sps=S, l1=l1, pad1=l1 // 2, l2=l2, L=L, C_levels=M, n_glob=n_glob, device=dev, y_lo=sr.y_lo, y_len=sr.y_len,
             sym_lo=sr.sym_lo, sym_cnt=sr.sym_cnt, own_lo=sr.own_lo, own_cnt=sr.own_cnt)
-rx, _ = nonlinear_isi_range(77, qam_constellation(M * M), S, 16.0, 0, B, B)
-y = np.stack((rx.real, rx.imag))[:, sr.y_lo:sr.y_lo + sr.y_len]
+rx, _ = nonlinear_isi_range(77, pam_constellation(M) if real else qam_constellation(M * M), S, 16.0, 0, B, B)
+y = (np.real(rx)[None, :] if real else np.stack((rx.real, rx.imag)))[:, sr.y_lo:sr.y_lo + sr.y_len]
 y = torch.from_numpy(np.ascontiguousarray(y)).float().to(dev)
 n = plan.sizes
 g = torch.Generator().manual_seed(5)
 params = (0.02 * torch.randn(sum(n), generator=g)).to(dev)
-params[L // 2] += 1.0; params[n[0] + n[1] + l1 // 2] += 1.0; params[-2 * M:] = 1.0
+params[L // 2] += 1.0; params[n[0] + n[1] + l1 // 2] += 1.0; params[-ns * M:] = 1.0
 grads, am, av, avm = (torch.zeros_like(params) for _ in range(4))
-lv = torch.arange(-(M - 1), M, 2, dtype=torch.float32, device=dev); levels = torch.stack((lv, lv)).contiguous()
+lv = torch.arange(-(M - 1), M, 2, dtype=torch.float32, device=dev); levels = torch.stack([lv] * ns).contiguous()
 prior = torch.full_like(levels, 1.0 / M); nv = torch.tensor([0.05], device=dev)
-xhat = torch.empty((2, sr.sym_cnt), device=dev); loss = torch.zeros(1, device=dev)
+xhat = torch.empty((ns, sr.sym_cnt), device=dev); loss = torch.zeros(1, device=dev)
 tr = ShardedTrainer(plan)
 kw = dict(y=y, levels=levels, prior=prior, params=params, grads=grads, adam_m=am, adam_v=av, adam_vmax=avm, noise_var=nv,
           xhat=xhat, loss_out=loss, lr=5e-3)
@@ -89,6 +91,25 @@ def test_two_rank_sharded_steps_equal_single_rank(tmp_path, shape):
         assert abs(float(r["nv"].reshape(-1)[0]) - float(one["nv"].reshape(-1)[0])) < 1e-6 * float(one["nv"].reshape(-1)[0])
     xs = np.concatenate([r["xhat"] for r in sorted(two, key=lambda r: int(r["own_lo"]))], axis=1)
     assert rel(xs, one["xhat"]) < 1e-6
+
+
+def test_real_model_on_matrix_cores_sharded_and_against_generic_kernels(tmp_path):
+    """The real (PAM) model on the matrix-core kernels (run ELBO kernel with a zero quadrature stream, one-product equaliser
+    backward, symmetric-form forward with sums in double): two ranks (non-zero own_lo / sym_lo / y_lo on rank 1) against one, and
+    one rank against the generic kernels."""
+    shape = (25, 2, 25, 25, 4, 3000)
+    one = _run_world(1, tmp_path, shape, tag="r1", V2VAE_REAL="1", V2VAE_REAL_MFMA="1")[0]
+    two = _run_world(2, tmp_path, shape, tag="r2", V2VAE_REAL="1", V2VAE_REAL_MFMA="1")
+    gen = _run_world(1, tmp_path, shape, tag="rg", V2VAE_REAL="1")[0]   # 3000 symbols without the flag: generic kernels
+    rel = lambda a, b: np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b.astype(np.float64))
+    for r in two:
+        assert rel(r["params"], one["params"]) < 2e-6
+        assert abs(float(r["loss"].reshape(-1)[0]) - float(one["loss"].reshape(-1)[0])) < 1e-6 * abs(float(one["loss"].reshape(-1)[0]))
+    xs = np.concatenate([r["xhat"] for r in sorted(two, key=lambda r: int(r["own_lo"]))], axis=1)
+    assert rel(xs, one["xhat"]) < 1e-6
+    assert rel(one["xhat"], gen["xhat"]) < 1e-6
+    assert rel(one["params"], gen["params"]) < 5e-6
+    assert abs(float(one["loss"].reshape(-1)[0]) - float(gen["loss"].reshape(-1)[0])) < 1e-6 * abs(float(gen["loss"].reshape(-1)[0]))
 
 
 def test_sharded_trainer_over_rccl_equals_single_gpu_step_bit_for_bit(tmp_path):
