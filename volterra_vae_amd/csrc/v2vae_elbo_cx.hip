@@ -482,7 +482,11 @@ __host__ __device__ constexpr int cx3_lds_floats(int S, int NK) {
     return S * 2 * NK * 64 + S * 64 + CX3_NW * CX3_WAVE_F;
 }
 
-// REAL: the real model (one stream).  The quadrature stream is identically zero - its samples read as zero, its moment planes are
+// REAL: the real model (one stream).  Everything that is identically zero with a zero quadrature stream is a compile-time zero in
+// the REAL instances (Q = H X's second half, the quadrature means / 3rd moments, Im of the tables, the second residual, beta,
+// sigma), so its arithmetic folds away: H X takes 7 (8) instead of 13 (16) matrix steps, H w 8 instead of 13 (16), dE/dH one
+// product instead of three.
+// The quadrature stream is identically zero - its samples read as zero, its moment planes are
 // zero-filled by the soft demapper, the imaginary planes of the tables are zero - and the three terms of the reference's
 // diagonal quirk (lib/real_equalization.py:869: the mean uses diag(h2) where the second moment uses the diagonal d = 2 diag(h2) of
 // the symmetrised kernel) are added: with T_n = y'_n sum_x v_{n+x} d_x,  E += T_n,  dE/dv_{n+x} += y'_n d_x,  dE/dd_x += y'_n v_{n+x}.
@@ -639,7 +643,7 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
             const bool valid = (t < b) && n >= 0 && n < l.W;
             const bool own = valid && t >= a;
             const float mv = valid ? 1.f : 0.f, mo = own ? 1.f : 0.f;
-            const float y0 = yn0, y1 = yn1;
+            const float y0 = yn0, y1 = REAL ? 0.f : yn1;
             if (sub + 1 < nsl) { yn0 = load_y(t + 32, 0); yn1 = load_y(t + 32, 1); }
             store32(tsl + 16, 0);                    // symbols [tsl + 16, tsl + 48) complete what this slab reads
             fetch32(ts + tsl + 48);                  // the group the next slab (of this or of the next strip) will add
@@ -653,6 +657,7 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
                 if (2 * s + 1 < NK) off = 2 * s + h;
                 else if (2 * s >= NK) off = MS + 2 * s - NK + h;
                 else off = h ? MS : NK - 1;
+                if (REAL && 2 * s >= NK) continue;   // both k-slots of the step belong to the quadrature stream
                 U = MFMA32(Aop[s * 64], s_mu[tsl + i + off], U);
             }
             // operands of the first steps requested before the chain starts, then two reads per step (the constant A operands
@@ -668,7 +673,7 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
             // NK = 13: rows 13 of the product (upper lane half, accumulator slots 5 and 13) hold the first-order term of the window
             float a0 = 0.f, a1 = 0.f;
             if (NK == 13) {
-                a0 = h ? U[5] : 0.f; a1 = h ? U[13] : 0.f;
+                a0 = h ? U[5] : 0.f; a1 = (!REAL && h) ? U[13] : 0.f;
                 U[5] = h ? 0.f : U[5]; U[13] = h ? 0.f : U[13];
             }
             // per-tap algebra on tap PAIRS (2 p, 2 p + 1).  One address register per PAIR of planes (the offset field of a
@@ -685,10 +690,11 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const int xo = cx_kk(2 * p, 0);
-                const f2 P = f2{U[2 * p], U[2 * p + 1]}, Q = f2{U[2 * p + 8], U[2 * p + 9]};
-                const f2 ma = ldl(b0 + xo), mb = ldl(b0 + MS + xo), Sv = ldl(b2 + xo), dv = ldl(b2 + MS + xo);
-                const f2 ka = ldl(b4 + xo), kb = ldl(b4 + MS + xo), gs = ldl(b6 + xo);
-                const f2 hr = C2(0, p), hi = C2(1, p), dr = cdr[p], di = cdi[p];
+                const f2 zero2 = {0.f, 0.f};
+                const f2 P = f2{U[2 * p], U[2 * p + 1]}, Q = REAL ? zero2 : f2{U[2 * p + 8], U[2 * p + 9]};
+                const f2 ma = ldl(b0 + xo), mb = REAL ? zero2 : ldl(b0 + MS + xo), Sv = ldl(b2 + xo), dv = ldl(b2 + MS + xo);
+                const f2 ka = ldl(b4 + xo), kb = REAL ? zero2 : ldl(b4 + MS + xo), gs = ldl(b6 + xo);
+                const f2 hr = C2(0, p), hi = REAL ? zero2 : C2(1, p), dr = cdr[p], di = REAL ? zero2 : cdi[p];
                 const f2 zp = 2.f * P + hr, zq = 2.f * Q + hi;
                 if (NK != 13) {
                     a0v += hr * ma - hi * mb;
@@ -716,7 +722,7 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
             float sd0 = sd0v.x + sd0v.y;
             const float vs = cx_sum_halves(vsv.x + vsv.y);
             float e0 = cx_sum_halves((a0 + (q0v.x + q0v.y)) + sd0) - y0;
-            float e1 = cx_sum_halves((a1 + (q1v.x + q1v.y)) + (sd1v.x + sd1v.y)) - y1;
+            float e1 = REAL ? 0.f : cx_sum_halves((a1 + (q1v.x + q1v.y)) + (sd1v.x + sd1v.y)) - y1;
             if (REAL) sd0 = cx_sum_halves(sd0);
             if (own && h == 0) Eacc += (double)(e0 * e0 + e1 * e1 + vs + (REAL ? y0 * sd0 : 0.f));
             e0 *= mv; e1 *= mv;
@@ -726,7 +732,7 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
             f32x16 HW = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (NK == 16) {
 #pragma unroll
-                for (int s = 0; s < 16; ++s)
+                for (int s = 0; s < (REAL ? 8 : 16); ++s)   // (REAL: beta is zero)
                     HW = MFMA32(Aop[(NK + s) * 64], s < 8 ? al[(s & 7) >> 1][s & 1] : be[(s & 7) >> 1][s & 1], HW);
             } else {
                 // accumulator slots q = 0..4 of either lane half hold valid taps (0-3, 8 | 4-7, 12): ten steps take them as they
@@ -735,11 +741,12 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
 #pragma unroll
                 for (int s = 0; s < 5; ++s) HW = MFMA32(Aop[(NK + s) * 64], al[s >> 1][s & 1], HW);
 #pragma unroll
-                for (int s = 0; s < 5; ++s) HW = MFMA32(Aop[(NK + 5 + s) * 64], be[s >> 1][s & 1], HW);
+                for (int s = 0; s < (REAL ? 0 : 5); ++s) HW = MFMA32(Aop[(NK + 5 + s) * 64], be[s >> 1][s & 1], HW);
 #pragma unroll
                 for (int s = 5; s < 8; ++s) {
                     float x = al[s >> 1][s & 1], z = be[s >> 1][s & 1];
-                    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(z));   // x = (alpha of lanes 0-31 | beta of lanes 0-31)
+                    if (REAL) x = h ? 0.f : x;   // (alpha of lanes 0-31 | beta = 0)
+                    else asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(z));   // x = (alpha of lanes 0-31 | beta of lanes 0-31)
                     HW = MFMA32(Aop[(NK + 5 + s) * 64], x, HW);
                 }
             }
@@ -754,12 +761,14 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const int pr = cx_kk(2 * p, h) >> 1;
-                const f2 zp = zP[p], zq = zQ[p], dr = cdr[p], di = cdi[p];
+                const f2 zero2 = {0.f, 0.f};
+                const f2 zp = zP[p], zq = zQ[p], dr = cdr[p], di = REAL ? zero2 : cdi[p];
                 const f2 ed = 2.f * (e0 * dr + e1 * di);
                 const f2 da0 = (2.f * mv) * (e0 * zp + e1 * zq + f2{HW[2 * p], HW[2 * p + 1]});
-                const f2 db0 = (2.f * mv) * (e1 * zp - e0 * zq + f2{HW[2 * p + 8], HW[2 * p + 9]});
+                // (REAL: the gradients with respect to the quadrature moments are not read by anyone)
+                const f2 db0 = REAL ? zero2 : (2.f * mv) * (e1 * zp - e0 * zq + f2{HW[2 * p + 8], HW[2 * p + 9]});
                 f2 da1 = mv * (zz[p] + ed);
-                const f2 db1 = mv * (zz[p] - ed);
+                const f2 db1 = REAL ? zero2 : mv * (zz[p] - ed);
                 if (REAL) da1 += (mv * y0) * dr;
                 Bd[pr * 32 + i] = f32x4{da0.x, da0.y, db0.x, db0.y};
                 Bd[PB + pr * 32 + i] = f32x4{da1.x, da1.y, db1.x, db1.y};
@@ -801,7 +810,7 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 mav[p] = ldl(b0 + cx_kk(2 * p, 0));
-                mbv[p] = ldl(b0 + MS + cx_kk(2 * p, 0));
+                mbv[p] = REAL ? f2{0.f, 0.f} : ldl(b0 + MS + cx_kk(2 * p, 0));
             }
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
@@ -815,8 +824,10 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
                 const f2 t0 = mo * (gr + 2.f * al[p]), t1 = mo * (gi + 2.f * be[p]);
                 Tr[i * 17 + x] = t0.x;
                 Tr[i * 17 + x + 1] = t0.y;
-                Ts[i * 17 + x] = t1.x;
-                Ts[i * 17 + x + 1] = t1.y;
+                if (!REAL) {   // (sigma is zero)
+                    Ts[i * 17 + x] = t1.x;
+                    Ts[i * 17 + x + 1] = t1.y;
+                }
             }
             __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);   // the eight pairs of means requested together
 #pragma unroll
@@ -830,6 +841,10 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 const int w = 4 * s + kq;   // window of this lane's k-slot; tap i16
+                if (REAL) {   // sigma = 0, mu_b = 0: dE/dH = rho^T mu_a (K2 and K3 stay zero: Re = K1 - K3, Im = K1 + K2 is not read)
+                    K1 = MFMA16(Tr[w * 17 + i16], s_mu[tsl + w + i16], K1);
+                    continue;
+                }
                 const float rho = Tr[w * 17 + i16], sig = Ts[w * 17 + i16];
                 const float ma = s_mu[tsl + w + i16], mb = s_mu[MS + tsl + w + i16];
                 K1 = MFMA16(rho + sig, ma, K1);
