@@ -48,7 +48,7 @@ extern "C" {
 #define V2VAE_FLAG_GENERIC 1     /* the generic FMA kernels for every shape (no matrix-core / on-chip kernels) */
 #define V2VAE_FLAG_EQ_MFMA_FWD 2 /* complex, l2 <= 65: the matrix-core forward equaliser instead of the symmetric-form one */
 #define V2VAE_FLAG_REAL_MFMA 8   /* real model (mode 0): the matrix-core ELBO kernel and equaliser backward at every batch size (by default
-                                    only from 2^15 owned symbols on; smaller batches run the generic kernels) */
+                                    only from 2^12 owned symbols on; smaller batches run the generic kernels) */
 #define V2VAE_FLAG_ELBO_TILES 4  /* complex, <= 16 active taps per phase: the block-tile matrix-core ELBO kernel (workgroup barriers
                                     per tile) instead of the run kernel (every wave on its own run of windows); 17 or 33 active
                                     taps: whole blocks of 16 taps (2 or 3) instead of 1 or 2 blocks plus one tap on the side */

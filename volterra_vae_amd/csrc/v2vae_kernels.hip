@@ -140,7 +140,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     // the real model runs the same kernel on a zero quadrature stream (large batches; any batch on request)
     l.cx_real = (l.mode == 0 && l.ns == 1 && l.chan == 0 && l.LE <= 16 && l.S <= 2 &&
                  !(l.flags & (V2VAE_FLAG_GENERIC | V2VAE_FLAG_ELBO_TILES)) &&
-                 (l.own_cnt >= 32768 || (l.flags & V2VAE_FLAG_REAL_MFMA))) ? 1 : 0;
+                 (l.own_cnt >= 4096 || (l.flags & V2VAE_FLAG_REAL_MFMA))) ? 1 : 0;
     if (l.cx_real) l.use_cx = 1;
     l.cx_split = (l.use_cx && !(l.flags & V2VAE_FLAG_ELBO_TILES)) ? 1 : 0;
     {
