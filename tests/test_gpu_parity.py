@@ -124,10 +124,15 @@ def test_real_step_on_matrix_core_elbo_kernel_matches_reference_golden(name):
     assert rel(out["gx"], gen["gx"].cpu().numpy()) < 5e-6
 
 
-@pytest.mark.parametrize("L,S,l1,l2,B,M", [(15, 2, 25, 25, 40000, 4), (25, 2, 9, 5, 33000, 4), (13, 1, 5, 3, 50000, 2)])
+@pytest.mark.parametrize("L,S,l1,l2,B,M", [(15, 2, 25, 25, 40000, 4), (25, 2, 9, 5, 33000, 4), (13, 1, 5, 3, 50000, 2),
+                                           (15, 2, 5, 7, 6000, 4), (11, 2, 13, 17, 5000, 4), (9, 1, 3, 21, 4500, 2),
+                                           (25, 2, 31, 31, 7000, 4), (13, 2, 25, 41, 5000, 4), (7, 3, 1, 1, 4200, 4),
+                                           (15, 2, 9, 79, 4100, 4)])
 def test_real_large_batch_default_is_matrix_core_elbo_and_agrees_with_generic(L, S, l1, l2, B, M):
-    """From 2^15 owned symbols on the real model's ELBO runs on the matrix cores by default; the generic kernels (reference-pinned
-    by the goldens) on the same inputs are the check."""
+    """From 2^12 owned symbols on the real model runs on the matrix-core kernels by default; the generic kernels (reference-pinned
+    by the goldens) on the same inputs are the check.  The shapes reach every table width of the symmetric-form forward
+    equaliser (up to 9 / 17 / 25 / 31 lags), second-order kernels beyond it (generic forward, matrix-core backward) and a
+    first-order kernel longer than the second-order one (generic equaliser, matrix-core ELBO)."""
     from volterra_vae_amd import _lib
     from volterra_vae_amd.ops import Plan
     from volterra_vae_amd.synth import nonlinear_isi, pam_constellation
