@@ -149,12 +149,16 @@ def test_real_large_batch_default_is_matrix_core_elbo_and_agrees_with_generic(L,
     outs = []
     for flags in (0, _lib.FLAG_GENERIC):
         plan = Plan(ns=1, sps=S, l1=l1, pad1=l1 // 2, l2=l2, L=L, C_levels=M, n_glob=B * S, device="cuda", flags=flags)
-        o = run_step(plan, y, dev(h1), dev(h2), dev(k1), dev(k2), levels, prior, dev(sc), dev(np.array([0.06])))
-        outs.append(dict(E=float(o["E"]), loss=float(o["loss"]), gx=o["gx"].clone(), **{k: v.clone() for k, v in o["g"].items()}))
+        o = run_step(plan, y, dev(h1), dev(h2), dev(k1), dev(k2), levels, prior, dev(sc), dev(np.array([0.06])), want_q=True)
+        outs.append(dict(E=float(o["E"]), loss=float(o["loss"]), gx=o["gx"].clone(), xhat=o["xhat"].clone(), q=o["q"].clone(),
+                         **{k: v.clone() for k, v in o["g"].items()}))
     a, b = outs
     assert abs(a["E"] - b["E"]) < 2e-6 * abs(b["E"]) and abs(a["loss"] - b["loss"]) < 2e-6 * abs(b["loss"])
     for k in ("gx", "h1", "h2", "k1", "k2", "sc"):
         assert rel(a[k], b[k].cpu().numpy()) < 5e-6, k
+    # what inference returns (equalised symbols, posteriors) comes from the same two stages
+    assert rel(a["xhat"], b["xhat"].cpu().numpy()) < 2e-6
+    assert float((a["q"] - b["q"]).abs().max()) < 2e-5
 
 
 @pytest.mark.parametrize("name", STEP32)
