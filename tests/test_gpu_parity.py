@@ -365,3 +365,39 @@ def test_run_and_block_tile_elbo_kernels_agree(L, S, B):
     assert abs(a["E"] - b["E"]) < 1e-6 * abs(b["E"]) and abs(a["loss"] - b["loss"]) < 1e-6 * abs(b["loss"])
     for k in ("gx", "h1", "h2", "k1", "k2", "sc"):
         assert rel(a[k], b[k].cpu().numpy()) < 2e-6, k
+
+
+@pytest.mark.parametrize("ns,M,B", [(1, 4, 4096), (1, 4, 4099), (2, 4, 6000), (2, 8, 1001), (1, 2, 777), (2, 16, 2048), (1, 3, 5000)])
+def test_hard_decisions_equal_argmax_of_posteriors(ns, M, B):
+    """v2vae_decide against the arg-max of the soft demapper's posteriors (uniform prior, per-level noise scaling) and against
+    a direct evaluation of the reference's logits -(x - c)^2 / (sigma^2 s_c) (lib/real_equalization.py:816-823) in numpy;
+    lengths that are and are not multiples of four (16-byte and element-wise accesses)."""
+    from volterra_vae_amd.ops import Plan
+    rng = np.random.default_rng(5)
+    lv = np.arange(-(M - 1), M, 2).astype(np.float32)
+    levels = dev(np.stack([lv] * ns))
+    prior = torch.full_like(levels, 1.0 / M)
+    sc = dev(1.0 + 0.3 * rng.random((ns, M)))
+    nv = dev(np.array([0.2]))
+    x = (rng.choice(lv, size=(ns, B)) + 0.6 * rng.standard_normal((ns, B))).astype(np.float32)
+    xhat = dev(x)
+    plan = Plan(ns=ns, sps=2, l1=5, pad1=2, l2=3, L=7, C_levels=M, n_glob=B * 2, device="cuda")
+    q = torch.empty((ns, M, B), dtype=torch.float32, device="cuda")
+    plan.demap_moments(xhat, levels, prior, sc, nv, q)
+    dec = plan.decide(xhat, levels, sc, nv)
+    torch.cuda.synchronize()
+    assert dec.dtype == torch.int32 and dec.shape == (ns, B)
+    scn = sc.cpu().numpy().astype(np.float64)
+    z = -(x[:, None, :].astype(np.float64) - lv[None, :, None]) ** 2 / (0.2 * scn[:, :, None])
+    ref = np.argmax(z, axis=1)
+    d = dec.cpu().numpy()
+    # float32 logits can order two levels differently from float64 ones only where they tie to rounding
+    differ = d != ref
+    if differ.any():
+        zs = np.sort(z, axis=1)
+        gap = (zs[:, -1, :] - zs[:, -2, :])[differ]
+        assert np.all(gap < 1e-5 * np.abs(zs[:, -1, :][differ]) + 1e-6)
+    assert differ.mean() < 1e-4
+    qa = torch.argmax(q, dim=1).cpu().numpy()
+    agree = (d == qa).mean()
+    assert agree > 1 - 1e-4, agree

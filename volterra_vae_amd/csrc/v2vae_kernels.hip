@@ -645,21 +645,47 @@ __global__ __launch_bounds__(NT, CB <= 4 ? 4 : CB <= 8 ? 2 : 1) void k_demap_mom
     d_demap_moments<CB, EX>(GridCtx{(int)blockIdx.x, (int)gridDim.x}, l, xhat, levels, prior, scaling, noise_var, ws, q_out);
 }
 
+// hard decisions: arg-max over the levels of -(x - level)^2 / (noise variance x scaling), stream by stream; four symbols
+// per thread as one 16-byte load and one 16-byte store where the planes allow it
+template <int CB>
 __global__ __launch_bounds__(NT) void k_decide(Lay l, const float* __restrict__ xhat, const float* __restrict__ levels,
                                                const float* __restrict__ scaling, const float* __restrict__ noise_var,
                                                int32_t* __restrict__ dec) {
     const float nv = noise_var[0];
-    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < l.sym_cnt * l.ns; i += (int64_t)gridDim.x * NT) {
-        const int c = (int)(i / l.sym_cnt);
-        const float x = xhat[i];
-        float best = -INFINITY;
-        int arg = 0;
-        for (int k = 0; k < l.C; ++k) {
-            const float d = x - levels[c * l.C + k];
-            const float z = -(d * d) / (nv * scaling[c * l.C + k]);
-            if (z > best) { best = z; arg = k; }
+    const int64_t n = l.sym_cnt;
+    const bool vec = (n % 4 == 0) && (((reinterpret_cast<uintptr_t>(xhat) | reinterpret_cast<uintptr_t>(dec)) & 15) == 0);
+    const int64_t first = (int64_t)blockIdx.x * NT + threadIdx.x, stride = (int64_t)gridDim.x * NT;
+    for (int c = 0; c < l.ns; ++c) {
+        float lv[CB], den[CB];
+#pragma unroll
+        for (int k = 0; k < CB; ++k) {
+            const bool in = k < l.C;
+            lv[k] = in ? levels[c * l.C + k] : 0.f;
+            den[k] = in ? nv * scaling[c * l.C + k] : 1.f;
         }
-        dec[i] = arg;
+        auto pick = [&](float x) {
+            float best = -INFINITY;
+            int arg = 0;
+#pragma unroll
+            for (int k = 0; k < CB; ++k) {
+                const float d = x - lv[k];
+                const float z = -(d * d) / den[k];
+                if (k < l.C && z > best) { best = z; arg = k; }
+            }
+            return arg;
+        };
+        const float* __restrict__ xs = xhat + c * n;
+        int32_t* __restrict__ ds = dec + c * n;
+        if (vec) {
+            const float4* __restrict__ xv = reinterpret_cast<const float4*>(xs);
+            int4* __restrict__ dv = reinterpret_cast<int4*>(ds);
+            for (int64_t i = first; i < n / 4; i += stride) {
+                const float4 x = xv[i];
+                dv[i] = make_int4(pick(x.x), pick(x.y), pick(x.z), pick(x.w));
+            }
+        } else {
+            for (int64_t i = first; i < n; i += stride) ds[i] = pick(xs[i]);
+        }
     }
 }
 
@@ -1825,7 +1851,13 @@ int v2vae_decide(const v2vae_problem* p, const float* xhat, const float* levels,
     int rc = make_layout(p, &l);
     if (rc) return rc;
     if (!xhat || !levels || !scaling || !noise_var || !dec) return V2VAE_EINVAL;
-    hipLaunchKernelGGL(k_decide, dim3(l.nblk_sym), dim3(NT), 0, (hipStream_t)stream, l, xhat, levels, scaling, noise_var, dec);
+#define V2VAE_LAUNCH_DECIDE(CB) \
+    hipLaunchKernelGGL(k_decide<CB>, dim3(l.nblk_sym), dim3(NT), 0, (hipStream_t)stream, l, xhat, levels, scaling, noise_var, dec)
+    if (l.C <= 2) V2VAE_LAUNCH_DECIDE(2);
+    else if (l.C <= 4) V2VAE_LAUNCH_DECIDE(4);
+    else if (l.C <= 8) V2VAE_LAUNCH_DECIDE(8);
+    else V2VAE_LAUNCH_DECIDE(16);
+#undef V2VAE_LAUNCH_DECIDE
     return launch_status();
 }
 
