@@ -577,14 +577,15 @@ __device__ __forceinline__ double xhat_full(const Lay& l, const float* __restric
 // ------------------------------------------------------------------------------------------
 // soft demapping, moments, KL
 // ------------------------------------------------------------------------------------------
-// EX: exactly CB levels per stream and two streams, both known at compile time (no bounds checks, levels in registers)
-template <int CB, bool EX = false>
+// EX = 1 / 2: exactly CB levels per stream and one / two streams, both known at compile time (no bounds checks, levels in
+// registers); EX = 0: any level count up to CB, stream count from the layout
+template <int CB, int EX = 0>
 __device__ __forceinline__ void d_demap_moments(const GridCtx gc, Lay l, const float* __restrict__ xhat, const float* __restrict__ levels,
                                                       const float* __restrict__ prior, const float* __restrict__ scaling,
                                                       const float* __restrict__ noise_var, float* __restrict__ ws,
                                                       float* __restrict__ q_out) {
     __shared__ double red[NT / 64];
-    const int C = EX ? CB : l.C, NS = EX ? 2 : l.ns;
+    const int C = EX ? CB : l.C, NS = EX ? EX : l.ns;
     const float nv = noise_var[0];
     float* __restrict__ mom = ws + l.o_mom;
     double kl = 0.0;
@@ -616,7 +617,7 @@ __device__ __forceinline__ void d_demap_moments(const GridCtx gc, Lay l, const f
         for (int c = 0; c < 2; ++c) {
             if (c >= NS) break;
             Posterior p;
-            posterior<CB, EX>(xhat_full(l, ws, i, cx[c]), lvr[c], inv_den[c], C, p);
+            posterior<CB, (EX != 0)>(xhat_full(l, ws, i, cx[c]), lvr[c], inv_den[c], C, p);
             float* m = mom + (int64_t)c * 4 * l.sym_cnt + i;
             m[0] = p.mu; m[l.sym_cnt] = p.var; m[2 * l.sym_cnt] = p.kap; m[3 * l.sym_cnt] = p.gam;
             float klb = 0.f;
@@ -637,7 +638,7 @@ __device__ __forceinline__ void d_demap_moments(const GridCtx gc, Lay l, const f
     if (threadIdx.x == 0) reinterpret_cast<double*>(ws + l.o_KLpart)[gc.bid] = s;
 }
 
-template <int CB, bool EX>
+template <int CB, int EX>
 __global__ __launch_bounds__(NT, CB <= 4 ? 4 : CB <= 8 ? 2 : 1) void k_demap_moments(Lay l, const float* __restrict__ xhat, const float* __restrict__ levels,
                                                       const float* __restrict__ prior, const float* __restrict__ scaling,
                                                       const float* __restrict__ noise_var, float* __restrict__ ws,
@@ -692,15 +693,16 @@ __global__ __launch_bounds__(NT) void k_decide(Lay l, const float* __restrict__ 
 // ------------------------------------------------------------------------------------------
 // per-symbol backward
 // ------------------------------------------------------------------------------------------
-// EX: exactly CB levels per stream and two streams, both known at compile time (no bounds checks, levels in registers)
-template <int CB, bool EX = false>
+// EX = 1 / 2: exactly CB levels per stream and one / two streams, both known at compile time (no bounds checks, levels in
+// registers); EX = 0: any level count up to CB, stream count from the layout
+template <int CB, int EX = 0>
 __device__ __forceinline__ void d_sym_bwd(const GridCtx gc, Lay l, const float* __restrict__ xhat, const float* __restrict__ levels,
                                                 const float* __restrict__ prior, const float* __restrict__ scaling,
                                                 const float* __restrict__ noise_var, const double* __restrict__ scal,
                                                 const float* __restrict__ grad_scale, float* __restrict__ ws,
                                                 float* __restrict__ gxhat) {
     __shared__ float red[NT / 64][2 * MAX_C];
-    const int C = EX ? CB : l.C, NS = EX ? 2 : l.ns;
+    const int C = EX ? CB : l.C, NS = EX ? EX : l.ns;
     const float nv = noise_var[0];
     const float lam = (float)scal[V2VAE_SCAL_LAMBDA];
     const float gsc = grad_scale ? grad_scale[0] : 1.f;
@@ -775,7 +777,7 @@ __device__ __forceinline__ void d_sym_bwd(const GridCtx gc, Lay l, const float* 
                     const double x = xhat_full(l, ws, i, cx[c]);
                     const float* lv = lvr[c];
                     Posterior p;
-                    posterior<CB, EX>(x, lv, inv_den[c], C, p);
+                    posterior<CB, (EX != 0)>(x, lv, inv_den[c], C, p);
                     const float gmu = cg[c][0], gv = cg[c][1], gk = cg[c][2], gg = cg[c][3];
                     // Softmax backward in the pairwise form dz_k = q_k sum_j q_j (v_k - v_j): each term is a product of a
                     // (possibly tiny) probability with an O(1) difference, so nothing cancels against the posterior mean
@@ -830,7 +832,7 @@ __device__ __forceinline__ void d_sym_bwd(const GridCtx gc, Lay l, const float* 
     }
 }
 
-template <int CB, bool EX>
+template <int CB, int EX>
 __global__ __launch_bounds__(NT, CB <= 2 ? 4 : CB <= 4 ? 3 : CB <= 8 ? 2 : 1) void k_sym_bwd(Lay l, const float* __restrict__ xhat, const float* __restrict__ levels,
                                                 const float* __restrict__ prior, const float* __restrict__ scaling,
                                                 const float* __restrict__ noise_var, const double* __restrict__ scal,
@@ -1673,7 +1675,10 @@ __global__ __launch_bounds__(NT) void k_fit_persistent(Lay l, v2vae_fit_args a, 
             __syncthreads();
         }
         for (int b = 0; b < l.nblk_dm; ++b) {
-            d_demap_moments<CB>(GridCtx{b, l.nblk_dm}, l, xh, a.levels, a.prior, sc, nv, ws, nullptr);
+            // the same instantiation as the per-batch launch takes (bit-identical results)
+            if (l.C == CB && l.ns == 1) d_demap_moments<CB, 1>(GridCtx{b, l.nblk_dm}, l, xh, a.levels, a.prior, sc, nv, ws, nullptr);
+            else if (l.C == CB && l.ns == 2) d_demap_moments<CB, 2>(GridCtx{b, l.nblk_dm}, l, xh, a.levels, a.prior, sc, nv, ws, nullptr);
+            else d_demap_moments<CB, 0>(GridCtx{b, l.nblk_dm}, l, xh, a.levels, a.prior, sc, nv, ws, nullptr);
             __syncthreads();
         }
         for (int b = 0; b < l.nblk_elbo; ++b) {
@@ -1686,7 +1691,9 @@ __global__ __launch_bounds__(NT) void k_fit_persistent(Lay l, v2vae_fit_args a, 
         d_finalize_scalars(one, (double)l.W, scal);
         __syncthreads();
         for (int b = 0; b < l.nblk_sym; ++b) {
-            d_sym_bwd<CB>(GridCtx{b, l.nblk_sym}, l, xh, a.levels, a.prior, sc, nv, scal, nullptr, ws, gx);
+            if (l.C == CB && l.ns == 1) d_sym_bwd<CB, 1>(GridCtx{b, l.nblk_sym}, l, xh, a.levels, a.prior, sc, nv, scal, nullptr, ws, gx);
+            else if (l.C == CB && l.ns == 2) d_sym_bwd<CB, 2>(GridCtx{b, l.nblk_sym}, l, xh, a.levels, a.prior, sc, nv, scal, nullptr, ws, gx);
+            else d_sym_bwd<CB, 0>(GridCtx{b, l.nblk_sym}, l, xh, a.levels, a.prior, sc, nv, scal, nullptr, ws, gx);
             __syncthreads();
         }
         for (int b = 0; b < l.nblk_eq; ++b) {
@@ -1824,8 +1831,9 @@ int v2vae_demap_moments(const v2vae_problem* p, const float* xhat, const float* 
                        scaling, noise_var, (float*)ws, q_out)
 #define V2VAE_LAUNCH_DEMAP(CB)                                                     \
     do {                                                                           \
-        if (l.C == CB && l.ns == 2) V2VAE_LAUNCH_DEMAP_X(CB, true);                \
-        else V2VAE_LAUNCH_DEMAP_X(CB, false);                                      \
+        if (l.C == CB && l.ns == 2) V2VAE_LAUNCH_DEMAP_X(CB, 2);                   \
+        else if (l.C == CB && l.ns == 1) V2VAE_LAUNCH_DEMAP_X(CB, 1);              \
+        else V2VAE_LAUNCH_DEMAP_X(CB, 0);                                          \
     } while (0)
     if (l.C <= 2) V2VAE_LAUNCH_DEMAP(2);
     else if (l.C <= 4) V2VAE_LAUNCH_DEMAP(4);
@@ -1919,8 +1927,9 @@ int v2vae_sym_bwd(const v2vae_problem* p, const float* xhat, const float* levels
                        scaling, noise_var, scal, grad_scale, (float*)ws, gxhat)
 #define V2VAE_LAUNCH_SYMB(CB)                                                      \
     do {                                                                           \
-        if (l.C == CB && l.ns == 2) V2VAE_LAUNCH_SYMB_X(CB, true);                 \
-        else V2VAE_LAUNCH_SYMB_X(CB, false);                                       \
+        if (l.C == CB && l.ns == 2) V2VAE_LAUNCH_SYMB_X(CB, 2);                    \
+        else if (l.C == CB && l.ns == 1) V2VAE_LAUNCH_SYMB_X(CB, 1);               \
+        else V2VAE_LAUNCH_SYMB_X(CB, 0);                                           \
     } while (0)
     if (l.C <= 2) V2VAE_LAUNCH_SYMB(2);
     else if (l.C <= 4) V2VAE_LAUNCH_SYMB(4);
