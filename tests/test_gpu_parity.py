@@ -79,7 +79,7 @@ def _oracle_on_float32_inputs(g, S, lin):
 @pytest.mark.parametrize("name", [n for n in STEP32 if "S3" not in n])
 def test_real_step_on_matrix_core_elbo_kernel_matches_reference_golden(name):
     """The real model through the matrix-core ELBO kernel (a zero quadrature stream plus the diagonal-quirk terms; the default from
-    2^15 symbols on, forced here): the kernel the complex headline shape runs, pinned by the reference's own goldens."""
+    2^12 symbols on, forced here): the kernel the complex headline shape runs, pinned by the reference's own goldens."""
     from volterra_vae_amd import _lib
     from volterra_vae_amd.ops import Plan
     g32 = np.load(os.path.join(GOLDEN, f"v2vae_real_step_{name}.npz"))
