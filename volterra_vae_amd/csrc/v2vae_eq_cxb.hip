@@ -384,7 +384,20 @@ __global__ __launch_bounds__(NT, T <= 25 ? 4 : 3) void k_eq_fwd_sym(Lay l, const
             const float* __restrict__ sb = y + l.y_stride + loc0;
             eq_f2* dst = reinterpret_cast<eq_f2*>(tile);
             if (inside) {
-                for (int i = tid; i < tlen; i += NT) dst[i] = eq_f2{sa[i], sb[i]};
+                // six samples per thread requested before the first is written (one memory latency per tile, not one per sample)
+                for (int i0 = tid; i0 < tlen; i0 += 6 * NT) {
+                    eq_f2 v[6];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        const int i = i0 + k * NT;
+                        v[k] = i < tlen ? eq_f2{sa[i], sb[i]} : eq_f2{0.f, 0.f};
+                    }
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        const int i = i0 + k * NT;
+                        if (i < tlen) dst[i] = v[k];
+                    }
+                }
             } else {
                 for (int i = tid; i < tlen; i += NT) {
                     const int64_t g = g0 + i, loc = loc0 + i;
