@@ -33,7 +33,20 @@ __device__ __forceinline__ void eqcx_load_tile(const Lay& l, const float* __rest
     const float* __restrict__ sb = REAL ? sa : y + l.y_stride + loc0;
     f2* dst = reinterpret_cast<f2*>(tile);
     if (inside) {
-        for (int i = threadIdx.x; i < tl; i += NT) dst[i] = f2{sa[i], REAL ? 0.f : sb[i]};
+        // four samples per thread requested before the first is written (one memory latency per tile, not one per sample)
+        for (int i0 = threadIdx.x; i0 < tl; i0 += 4 * NT) {
+            f2 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + k * NT;
+                v[k] = i < tl ? f2{sa[i], REAL ? 0.f : sb[i]} : f2{0.f, 0.f};
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + k * NT;
+                if (i < tl) dst[i] = v[k];
+            }
+        }
     } else {
         for (int i = threadIdx.x; i < tl; i += NT) {
             const int64_t g = g0 + i, loc = loc0 + i;
