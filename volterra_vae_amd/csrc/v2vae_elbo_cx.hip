@@ -1090,13 +1090,29 @@ __global__ __launch_bounds__(NT, 5) void k_g2_cx(Lay l, float* __restrict__ ws) 
     for (int64_t tile = bid; tile < ntile; tile += nb) {
         const int64_t m0 = l.own_lo + tile * G2_TILE;
         __syncthreads();
-        for (int e = threadIdx.x; e < G2_TILE + 2 * HALO; e += NT) {
-            const int64_t m = m0 - HALO + e;
-            const bool in = m >= l.sym_lo && m < sym_hi;
-            const float* g = mom + (m - l.sym_lo);
-            s_mq[0][e & 3][e >> 2] = in ? g[0] : 0.f;
-            s_mq[1][e & 3][e >> 2] = in ? g[4 * st] : 0.f;
-            s_mq[2][e & 3][e >> 2] = in ? g[st] + g[5 * st] : 0.f;
+        {   // all of a thread's staged values are requested before the first is written (one memory latency per tile)
+            constexpr int NST = (G2_TILE + 2 * HALO + NT - 1) / NT;
+            float va[NST], vb[NST], vs[NST], vt[NST];
+#pragma unroll
+            for (int k = 0; k < NST; ++k) {
+                const int e = threadIdx.x + k * NT;
+                const int64_t m = m0 - HALO + e;
+                const bool in = e < G2_TILE + 2 * HALO && m >= l.sym_lo && m < sym_hi;
+                const float* g = mom + (m - l.sym_lo);
+                va[k] = in ? g[0] : 0.f;
+                vb[k] = in ? g[4 * st] : 0.f;
+                vs[k] = in ? g[st] : 0.f;
+                vt[k] = in ? g[5 * st] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < NST; ++k) {
+                const int e = threadIdx.x + k * NT;
+                if (e < G2_TILE + 2 * HALO) {
+                    s_mq[0][e & 3][e >> 2] = va[k];
+                    s_mq[1][e & 3][e >> 2] = vb[k];
+                    s_mq[2][e & 3][e >> 2] = vs[k] + vt[k];
+                }
+            }
         }
         __syncthreads();
         // thread t owns symbols m0 + 4 t .. + 3; the windows of means and of s slide through registers
