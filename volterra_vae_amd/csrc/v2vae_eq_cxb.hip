@@ -499,7 +499,20 @@ __global__ __launch_bounds__(NT, 2) void k_eq_fwd_symr(Lay l, const float* __res
             const bool inside = g0 >= 0 && g0 + tlen <= l.n_glob && loc0 >= 0 && loc0 + tlen <= l.y_len;   // uniform
             const float* __restrict__ sa = y + loc0;
             if (inside) {
-                for (int i = tid; i < tlen; i += NT) tile[i] = sa[i];
+                // six samples per thread requested before the first is written (one memory latency per tile, not one per sample)
+                for (int i0 = tid; i0 < tlen; i0 += 6 * NT) {
+                    float v[6];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        const int i = i0 + k * NT;
+                        v[k] = i < tlen ? sa[i] : 0.f;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        const int i = i0 + k * NT;
+                        if (i < tlen) tile[i] = v[k];
+                    }
+                }
             } else {
                 for (int i = tid; i < tlen; i += NT) {
                     const int64_t g = g0 + i, loc = loc0 + i;

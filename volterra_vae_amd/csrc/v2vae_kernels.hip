@@ -1321,8 +1321,18 @@ __device__ __forceinline__ void d_reduce_scalars(const GridCtx gc, Lay l, const 
     const double* Ep = reinterpret_cast<const double*>(ws + l.o_Epart);
     const double* Kp = reinterpret_cast<const double*>(ws + l.o_KLpart);
     double e = 0.0, k = 0.0;
-    for (int i = threadIdx.x; i < l.nblk_E; i += NT) e += Ep[i];
-    for (int i = threadIdx.x; i < l.nblk_dm; i += NT) k += Kp[i];
+    // up to four partial sums of either kind per thread in flight at once; added in index order
+    for (int i0 = threadIdx.x; i0 < l.nblk_E || i0 < l.nblk_dm; i0 += 4 * NT) {
+        double ve[4], vk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * NT;
+            ve[u] = i < l.nblk_E ? Ep[i] : 0.0;
+            vk[u] = i < l.nblk_dm ? Kp[i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { e += ve[u]; k += vk[u]; }
+    }
     const double es = block_sum_double(e, red);
     const double ks = block_sum_double(k, red);
     if (threadIdx.x == 0) { scal[V2VAE_SCAL_E] = es; scal[V2VAE_SCAL_KL] = ks; }
