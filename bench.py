@@ -36,10 +36,12 @@ def algorithmic_flops_per_symbol(L, S, l1, l2, cplx):
     i.e. only work the kernels actually execute is counted (the stacked real-valued formulation would be 48 Le^2)."""
     c = 4 if cplx else 1
     return {
-        # complex, up to 31 lags: symmetric form, l2 (l2 + 1) / 2 + l2 complex multiply-adds (first-order kernel folded in)
-        "eq_fwd": 8 * (l2 * (l2 + 1) // 2 + l2) if (cplx and l2 <= 31) else c * (2 * l1 + 2 * l2 * l2 + 2 * l2),
-        # the gradient planes are symmetric in the lag pair: the same count (the kernel accumulates 3 of 4 16x16 blocks)
-        "eq_bwd": 8 * (l2 * (l2 + 1) // 2 + l2) if (cplx and l2 <= 31) else c * (2 * l1 + 2 * l2 * l2),
+        # complex, up to 65 lags (k_eq_fwd_sym): symmetric form, l2 (l2 + 1) / 2 + l2 complex multiply-adds (first-order kernel
+        # folded in); beyond that the full lag matrix is evaluated
+        "eq_fwd": 8 * (l2 * (l2 + 1) // 2 + l2) if (cplx and l2 <= 65) else c * (2 * l1 + 2 * l2 * l2 + 2 * l2),
+        # the gradient planes are symmetric in the lag pair: the same count (k_eq_bwd_cx, up to 79 lags, accumulates the upper-
+        # triangular 16x16 blocks only)
+        "eq_bwd": 8 * (l2 * (l2 + 1) // 2 + l2) if (cplx and l2 <= 79) else c * (2 * l1 + 2 * l2 * l2),
         "elbo_fused": (24 if cplx else 12) * L * L / S,
     }
 
