@@ -568,10 +568,10 @@ __global__ __launch_bounds__(NT) void k_eq_fwd(Lay l, const float* __restrict__ 
 
 // The equaliser output at local symbol i in double: the float the caller holds plus, if that float is bitwise the one the
 // forward kernel produced, the remainder the kernel kept (real path only; otherwise just the float).
-__device__ __forceinline__ double xhat_full(const Lay& l, const float* __restrict__ ws, int64_t i, float x) {
+// `hi`, `lo`: planes o_xhi / o_xlo at the symbol, fetched ahead by the caller (anything when the layout has no remainder).
+__device__ __forceinline__ double xhat_full(const Lay& l, float x, float hi, float lo) {
     if (!l.xlo) return (double)x;
-    const float hi = ws[l.o_xhi + i];
-    return __float_as_uint(hi) == __float_as_uint(x) ? (double)x + (double)ws[l.o_xlo + i] : (double)x;
+    return __float_as_uint(hi) == __float_as_uint(x) ? (double)x + (double)lo : (double)x;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -604,20 +604,28 @@ __device__ __forceinline__ void d_demap_moments(const GridCtx gc, Lay l, const f
         }
     const int64_t stride = (int64_t)gc.nb * NT;
     float nx[2] = {0.f, 0.f};   // the next symbol's samples, requested one iteration ahead
+    float nhi = 0.f, nlo = 0.f; // and, one-stream model, the copy and the float remainder of its equaliser output
     {
         const int64_t i0 = (int64_t)gc.bid * NT + threadIdx.x;
-        if (i0 < l.sym_cnt) { nx[0] = xhat[i0]; if (NS > 1) nx[1] = xhat[l.sym_cnt + i0]; }
+        if (i0 < l.sym_cnt) {
+            nx[0] = xhat[i0]; if (NS > 1) nx[1] = xhat[l.sym_cnt + i0];
+            if (l.xlo) { nhi = ws[l.o_xhi + i0]; nlo = ws[l.o_xlo + i0]; }
+        }
     }
     for (int64_t i = (int64_t)gc.bid * NT + threadIdx.x; i < l.sym_cnt; i += stride) {
         const int64_t b = l.sym_lo + i;
         const bool in_kl = b >= l.kl_lo && b < l.kl_hi && b >= l.own_lo && b < l.own_lo + l.own_cnt;
         const float cx[2] = {nx[0], nx[1]};
-        if (i + stride < l.sym_cnt) { nx[0] = xhat[i + stride]; if (NS > 1) nx[1] = xhat[l.sym_cnt + i + stride]; }
+        const float chi = nhi, clo = nlo;
+        if (i + stride < l.sym_cnt) {
+            nx[0] = xhat[i + stride]; if (NS > 1) nx[1] = xhat[l.sym_cnt + i + stride];
+            if (l.xlo) { nhi = ws[l.o_xhi + i + stride]; nlo = ws[l.o_xlo + i + stride]; }
+        }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             if (c >= NS) break;
             Posterior p;
-            posterior<CB, (EX != 0)>(xhat_full(l, ws, i, cx[c]), lvr[c], inv_den[c], C, p);
+            posterior<CB, (EX != 0)>(xhat_full(l, cx[c], chi, clo), lvr[c], inv_den[c], C, p);
             float* m = mom + (int64_t)c * 4 * l.sym_cnt + i;
             m[0] = p.mu; m[l.sym_cnt] = p.var; m[2 * l.sym_cnt] = p.kap; m[3 * l.sym_cnt] = p.gam;
             float klb = 0.f;
@@ -731,11 +739,13 @@ __device__ __forceinline__ void d_sym_bwd(const GridCtx gc, Lay l, const float* 
         }
     // the loads of the next symbol are issued before the arithmetic of this one (the arithmetic is long enough to cover them)
     float nx[2], ng[2][4];
+    float nhi = 0.f, nlo = 0.f;   // one-stream model: the copy and the float remainder of the equaliser output
     const bool cx_path = l.use_cx || l.use_cxb;
     const float g4c = cx_path ? ws[l.o_g2c + 2] : 0.f;
     auto fetch = [&](int64_t i) {
         const int64_t b = l.sym_lo + i;
         const bool own = i < l.sym_cnt && b >= l.own_lo && b < l.own_lo + l.own_cnt;
+        if (own && l.xlo) { nhi = ws[l.o_xhi + i]; nlo = ws[l.o_xlo + i]; }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             nx[c] = 0.f; ng[c][0] = 0.f; ng[c][1] = 0.f; ng[c][2] = 0.f; ng[c][3] = 0.f;
@@ -768,13 +778,14 @@ __device__ __forceinline__ void d_sym_bwd(const GridCtx gc, Lay l, const float* 
         float cx[2], cg[2][4];
 #pragma unroll
         for (int c = 0; c < 2; ++c) { cx[c] = nx[c]; cg[c][0] = ng[c][0]; cg[c][1] = ng[c][1]; cg[c][2] = ng[c][2]; cg[c][3] = ng[c][3]; }
+        const float chi = nhi, clo = nlo;
         fetch(i + stride);
 #pragma unroll
         for (int c = 0; c < 2; ++c)
             if (c < NS) {
                 float gx = 0.f;
                 if (own) {
-                    const double x = xhat_full(l, ws, i, cx[c]);
+                    const double x = xhat_full(l, cx[c], chi, clo);
                     const float* lv = lvr[c];
                     Posterior p;
                     posterior<CB, (EX != 0)>(x, lv, inv_den[c], C, p);
