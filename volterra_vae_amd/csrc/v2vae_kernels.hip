@@ -477,16 +477,23 @@ __global__ __launch_bounds__(NT) void k_prep_tables(Lay l, const float* __restri
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void load_sample_tile(const Lay& l, const float* __restrict__ y, int64_t g0, float* tile) {
     // tile[c][i] = y_c[g0 + i] (0 outside the batch), i in [0, tile_len)
+    // four samples per thread are requested before the first is written (one memory latency per group, not per sample)
     const int n = l.ns * l.tile_len;
-    for (int idx = threadIdx.x; idx < n; idx += NT) {
-        const int c = idx / l.tile_len, i = idx - c * l.tile_len;
-        const int64_t g = g0 + i;
-        float v = 0.f;
-        if (g >= 0 && g < l.n_glob) {
-            const int64_t loc = g - l.y_lo;
-            if (loc >= 0 && loc < l.y_len) v = y[(int64_t)c * l.y_stride + loc];
+    for (int idx0 = threadIdx.x; idx0 < n; idx0 += 4 * NT) {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = idx0 + k * NT;
+            const int c = idx / l.tile_len, i = idx - c * l.tile_len;
+            const int64_t g = g0 + i, loc = g - l.y_lo;
+            const bool in = idx < n && g >= 0 && g < l.n_glob && loc >= 0 && loc < l.y_len;
+            v[k] = in ? y[(int64_t)c * l.y_stride + loc] : 0.f;
         }
-        tile[idx] = v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = idx0 + k * NT;
+            if (idx < n) tile[idx] = v[k];
+        }
     }
 }
 
@@ -1040,10 +1047,20 @@ __device__ __forceinline__ void d_elbo(const GridCtx gc, Lay l, const float* __r
             const int64_t tbase = s0 - l.kmax;
             __syncthreads();
             // ---- A: stage moments and window data
-            for (int idx = tid; idx < NS * 4 * TSYM; idx += NT) {
-                const int cq = idx / TSYM, ms = idx - cq * TSYM;
-                const int64_t m = tbase + ms;
-                s_mom[idx] = (m >= l.sym_lo && m < sym_hi) ? mom[(int64_t)cq * l.sym_cnt + (m - l.sym_lo)] : 0.f;
+            for (int idx0 = tid; idx0 < NS * 4 * TSYM; idx0 += 4 * NT) {   // four loads in flight per thread
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int idx = idx0 + k * NT;
+                    const int cq = idx / TSYM, ms = idx - cq * TSYM;
+                    const int64_t m = tbase + ms;
+                    v[k] = (idx < NS * 4 * TSYM && m >= l.sym_lo && m < sym_hi) ? mom[(int64_t)cq * l.sym_cnt + (m - l.sym_lo)] : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int idx = idx0 + k * NT;
+                    if (idx < NS * 4 * TSYM) s_mom[idx] = v[k];
+                }
             }
             if (tid < TW) {
                 const int64_t t = tbase + tid;
