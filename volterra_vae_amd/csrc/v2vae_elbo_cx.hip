@@ -515,7 +515,8 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
     const float* __restrict__ mom = ws + l.o_mom;
     const int64_t own_hi = l.own_lo + l.own_cnt, sym_hi = l.sym_lo + l.sym_cnt, st = l.sym_cnt;
 
-    // ---- constants of every phase into LDS
+    // ---- constants of every phase into LDS (compile-time trip count: unrolled, so that the loads of all passes are in flight together)
+#pragma unroll
     for (int idx = tid; idx < S * 2 * NK * 64; idx += CX3_NT) {
         const int ln = idx & 63, s = (idx >> 6) % (2 * NK), rr = idx / (2 * NK * 64);
         const int jj = ln & 31, hh = ln >> 5, cjj = jj >> 4, yjj = jj & 15;
