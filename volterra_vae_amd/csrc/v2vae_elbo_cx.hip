@@ -1052,8 +1052,18 @@ __global__ __launch_bounds__(NT, 5) void k_g2_cx(Lay l, float* __restrict__ ws) 
             const int d = threadIdx.x % NLAG, c = threadIdx.x / NLAG;
             const double* part = reinterpret_cast<const double*>(ws + l.o_psum_part);
             double s = 0.0;
-            if (c < nchunk)
-                for (int b = c; b < l.nblk_psum; b += nchunk) s += part[(size_t)b * NLAG + d];
+            if (c < nchunk) {
+                // eight loads in flight, added in workgroup order
+                int b = c;
+                for (; b + 7 * nchunk < l.nblk_psum; b += 8 * nchunk) {
+                    double v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(b + u * nchunk) * NLAG + d];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s += v[u];
+                }
+                for (; b < l.nblk_psum; b += nchunk) s += part[(size_t)b * NLAG + d];
+            }
             s_pp[threadIdx.x] = s;
             __syncthreads();
             if (threadIdx.x < NLAG) {

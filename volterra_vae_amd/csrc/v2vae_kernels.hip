@@ -177,7 +177,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
         if (!l.use_cx && !l.use_cxb && !generic_elbo_ok) return V2VAE_ESIZE;
         l.generic_elbo_ok = generic_elbo_ok;
         int64_t nb = (l.own_cnt + NT - 1) / NT;
-        l.nblk_psum = (int)(nb < 512 ? nb : 512);
+        l.nblk_psum = (int)(nb < 2048 ? nb : 2048);
     }
     // ---- matrix-core equaliser path: complex, second-order lags odd <= 31, centred first-order window inside it
     l.use_eqcx = (l.mode == 1 && l.l2 >= 1 && l.l2 <= 31 && (l.l1 & 1) && l.l1 <= l.l2 && l.pad1 == l.l1 / 2 &&
