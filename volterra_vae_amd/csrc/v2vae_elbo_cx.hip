@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include "v2vae_cx_common.h"
+#include "v2vae_chain_cx.h"
 #include "v2vae_layout.h"
 
 namespace v2vae {
@@ -1238,50 +1239,11 @@ __global__ __launch_bounds__(NT, 5) void k_g2_cx(Lay l, float* __restrict__ ws) 
     }
 }
 
-// raw gradients of the complex channel kernels from the per-phase totals
+// raw gradients of the complex channel kernels from the per-phase totals (body: v2vae_chain_cx.h)
 __global__ __launch_bounds__(NT) void k_chain_channel_cx(Lay l, const float* __restrict__ ws, const double* __restrict__ scal,
                                                          const float* __restrict__ grad_scale, float* __restrict__ g_h1,
                                                          float* __restrict__ g_h2) {
-    const float lam = (float)scal[V2VAE_SCAL_LAMBDA] * (grad_scale ? grad_scale[0] : 1.f);
-    const int np = l.cx_real ? 1 : 2;   // parameter planes (Re, Im; the real model has one)
-    const int L = l.L, n1 = np * L, n2 = np * L * L;
-    auto compact = [&](int tap, int* r, int* x) {
-        int rr = (tap - (L - 1)) % l.S;
-        if (rr < 0) rr += l.S;
-        *r = rr;
-        *x = (rr + L - 1 - tap) / l.S;
-    };
-    for (int idx = blockIdx.x * NT + threadIdx.x; idx < n1 + n2; idx += gridDim.x * NT) {
-        if (idx < n1) {
-            if (!g_h1) continue;
-            const int p = idx / L, tap = idx - p * L;
-            int r, x;
-            compact(tap, &r, &x);
-            g_h1[idx] = lam * ws[l.o_tot_cx + (size_t)r * CX_REC + 512 + p * 16 + x];
-        } else {
-            if (!g_h2) continue;
-            const int e = idx - n1;
-            const int p = e / (L * L), rem = e - p * L * L;
-            const int ti = rem / L, tj = rem - ti * L;
-            int ri, xi, rj, xj;
-            compact(ti, &ri, &xi);
-            compact(tj, &rj, &xj);
-            float v = 0.f;
-            if (ri == rj) {
-                const float* tot = ws + l.o_tot_cx + (size_t)ri * CX_REC;
-                const float* Hp = ws + l.o_cxH + (size_t)(ri * 2 + p) * 256;
-                const float ps = ws[l.o_psv + ((size_t)ri * l.LE + xi) * l.LE + xj];   // lagged sum of the tap pair (k_g2_cx)
-                auto G = [&](int a, int b) {
-                    float g = tot[p * 256 + a * 16 + b];
-                    g += 4.f * Hp[a * 16 + b] * ps;
-                    if (a == b) g += tot[512 + (2 + p) * 16 + a];
-                    return g;
-                };
-                v = G(xi, xj) + G(xj, xi);
-            }
-            g_h2[e] = lam * v;
-        }
-    }
+    d_chain_channel_cx(l, ws, scal, grad_scale, g_h1, g_h2, (int)blockIdx.x, (int)gridDim.x);
 }
 
 template <typename K>

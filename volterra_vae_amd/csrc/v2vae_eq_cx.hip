@@ -12,6 +12,7 @@
 // Applies when mode = complex, l2 odd <= 79, l1 odd <= l2 and pad1 = l1 / 2 (lag rows in 1 .. 5 blocks of 16).
 #include <hip/hip_runtime.h>
 
+#include "v2vae_chain_cx.h"
 #include "v2vae_layout.h"
 
 namespace v2vae {
@@ -173,28 +174,10 @@ __global__ __launch_bounds__(NT, NB16 <= 3 ? 4 : 2) void k_eq_bwd_cx(Lay l, cons
     for (int e = tid; e < 2 * LD * LD; e += NT) rec[e] = img[e];
 }
 
+// chain rule of the equaliser gradients (body: v2vae_chain_cx.h)
 __global__ __launch_bounds__(NT) void k_chain_equaliser_cx(Lay l, const float* __restrict__ ws, float* __restrict__ g_k1,
                                                            float* __restrict__ g_k2) {
-    const float* T = ws + l.o_tot_eqcx;
-    const int l1 = l.l1, l2 = l.l2, LD = 16 * l.eqb16, PL = LD * LD;
-    const int n1 = l.ns * l1, n2 = l.ns * l2 * l2;   // two parameter planes (Re, Im); the real model has one
-    auto GK = [&](int p, int a, int b) {  // dE/dK (effective symmetric kernel), plane p: a lower block is its partner transposed
-        return (a >> 4) > (b >> 4) ? T[p * PL + b * LD + a] : T[p * PL + a * LD + b];
-    };
-    for (int idx = blockIdx.x * NT + threadIdx.x; idx < n1 + n2; idx += gridDim.x * NT) {
-        if (idx < n1) {
-            if (!g_k1) continue;
-            const int p = idx / l1, jj = idx - p * l1;
-            const int x = l.pad1 + l.p2 - jj;  // lag row that first-order tap jj multiplies (x < l2)
-            g_k1[idx] = T[p * PL + x * LD + l2];
-        } else {
-            if (!g_k2) continue;
-            const int e = idx - n1;
-            const int p = e / (l2 * l2), rem = e - p * l2 * l2;
-            const int a = rem / l2, b = rem - a * l2;
-            g_k2[e] = GK(p, a, b) + GK(p, b, a);
-        }
-    }
+    d_chain_equaliser_cx(l, ws, g_k1, g_k2, (int)blockIdx.x, (int)gridDim.x);
 }
 
 int launch_eq_bwd_cx(const Lay& l, const float* y, const float* gx, float* ws, hipStream_t st) {

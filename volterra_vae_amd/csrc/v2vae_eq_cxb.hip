@@ -43,59 +43,7 @@ __device__ __forceinline__ void eqcxb_load_tile(const Lay& l, const float* __res
     }
 }
 
-// A-operand table of the forward: tab[step][row block][plane (Zr, Zi)][64 lanes], followed by the first-order kernel on lag
-// indices: k1w[plane][NBL * 32] with k1w[x] = k1[pad1 + p2 - x]
-__global__ __launch_bounds__(NT) void k_prep_eqcxb(Lay l, const float* __restrict__ k1, const float* __restrict__ k2,
-                                                   float* __restrict__ ws) {
-    const int l1 = l.l1, l2 = l.l2, p1 = l.pad1, p2 = l.p2, LK = l.eqcx_lk, NBL = l.eqcxb_nbl;
-    const float* k1r = k1;
-    const float* k1i = k1 + l1;
-    const float* k2r = k2;
-    const float* k2i = k2 + (size_t)l2 * l2;
-    const int n = l.eqcx_steps * NBL * 2 * 64;
-    for (int idx = blockIdx.x * NT + threadIdx.x; idx < n; idx += gridDim.x * NT) {
-        const int lane = idx & 63, plane = (idx >> 6) & 1, jb = (idx >> 7) % NBL, s = idx / (128 * NBL);
-        const int j = jb * 32 + (lane & 31), h = lane >> 5;
-        const int k = 2 * s + h, ck = k >= LK ? 1 : 0, x = k - ck * LK;  // stacked input lag (stream ck, lag x)
-        float v = 0.f;
-        if (x < l2) {
-            if (j < l2) {
-                const float kr = k2r[x * l2 + j] + k2r[j * l2 + x], ki = k2i[x * l2 + j] + k2i[j * l2 + x];
-                v = ck == 0 ? (plane == 0 ? kr : ki) : (plane == 0 ? -ki : kr);  // [[Kr, Ki], [-Ki, Kr]]
-            }
-        }
-        ws[l.o_eqcxbA + idx] = v;
-    }
-    for (int idx = blockIdx.x * NT + threadIdx.x; idx < 2 * NBL * 32; idx += gridDim.x * NT) {
-        const int plane = idx / (NBL * 32), x = idx - plane * NBL * 32;
-        const int jj = p1 + p2 - x;  // first-order tap that multiplies lag x
-        ws[l.o_eqcxbA + n + idx] = (x < l2 && jj >= 0 && jj < l1) ? (plane == 0 ? k1r[jj] : k1i[jj]) : 0.f;
-    }
-    if (l.eqsym_t) {   // table of the symmetric-form forward kernel (k_eq_fwd_sym): one stream of (Re, Im) entries, row after row,
-                       // row a = [first-order weight of lag a, K'_aa, K'_a,a+1, ..., K'_a,T-1]; eight zero entries pad the end
-        const int T = l.eqsym_t, ne = T * (T + 1) / 2 + T;
-        for (int idx = blockIdx.x * NT + threadIdx.x; idx < ne + 8; idx += gridDim.x * NT) {
-            float vr = 0.f, vi = 0.f;
-            if (idx < ne) {
-                int a = 0, rem = idx;
-                while (rem >= T - a + 1) { rem -= T - a + 1; ++a; }
-                if (rem == 0) {
-                    const int jj = p1 + p2 - a;  // first-order tap that multiplies lag a
-                    if (a < l2 && jj >= 0 && jj < l1) { vr = k1r[jj]; vi = k1i[jj]; }
-                } else {
-                    const int b = a + rem - 1;
-                    if (b < l2) {
-                        const float sc = a == b ? 1.f : 2.f;   // K_ab y_a y_b + K_ba y_b y_a
-                        vr = sc * (k2r[a * l2 + b] + k2r[b * l2 + a]);
-                        vi = sc * (k2i[a * l2 + b] + k2i[b * l2 + a]);
-                    }
-                }
-            }
-            ws[l.o_eqsym + 2 * idx] = vr;
-            ws[l.o_eqsym + 2 * idx + 1] = vi;
-        }
-    }
-}
+// (the tables of the forward kernels are built by d_prep_eqcxb, v2vae_prep_eq.h, inside the launch that prepares every table)
 
 template <int NBL>
 __global__ __launch_bounds__(NT) void k_eq_fwd_cxb(Lay l, const float* __restrict__ y, const float* __restrict__ ws,
@@ -318,11 +266,6 @@ __global__ __launch_bounds__(NT) void k_chain_equaliser_cxb(Lay l, const float* 
             g_k2[e] = v;
         }
     }
-}
-
-int launch_prep_eqcxb(const Lay& l, const float* k1, const float* k2, float* ws, hipStream_t st) {
-    hipLaunchKernelGGL(k_prep_eqcxb, dim3(32), dim3(NT), 0, st, l, k1, k2, ws);
-    return V2VAE_OK;
 }
 
 // Forward equaliser in symmetric form on the vector pipe, for kernels of up to 65 lags (instances 9, 17, 25, 31, 47, 65):

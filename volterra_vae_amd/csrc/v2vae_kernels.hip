@@ -14,8 +14,10 @@
 
 #include <mutex>
 
+#include "v2vae_chain_cx.h"
 #include "v2vae_layout.h"
 #include "v2vae_posterior.h"
+#include "v2vae_prep_eq.h"
 
 namespace v2vae {
 
@@ -470,6 +472,14 @@ __global__ __launch_bounds__(NT) void k_prep_tables(Lay l, const float* __restri
                                                     const float* __restrict__ k1, const float* __restrict__ k2,
                                                     float* __restrict__ ws) {
     d_prep_tables(GridCtx{(int)blockIdx.x, (int)gridDim.x}, l, h1, h2, k1, k2, ws);
+}
+
+// the same plus, in PREP_EQCXB_BLOCKS further workgroups, the tables of the complex forward equaliser kernels (one launch)
+__global__ __launch_bounds__(NT) void k_prep_tables_eq(Lay l, const float* __restrict__ h1, const float* __restrict__ h2,
+                                                       const float* __restrict__ k1, const float* __restrict__ k2,
+                                                       float* __restrict__ ws, int nb_tab) {
+    if ((int)blockIdx.x < nb_tab) d_prep_tables(GridCtx{(int)blockIdx.x, nb_tab}, l, h1, h2, k1, k2, ws);
+    else d_prep_eqcxb(l, k1, k2, ws, (int)blockIdx.x - nb_tab, (int)gridDim.x - nb_tab);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1848,8 +1858,12 @@ int v2vae_prep_tables(const v2vae_problem* p, const float* h1, const float* h2, 
     if (rc) return rc;
     // either group may be absent (NULL): channel tables need h1 and h2, equaliser tables k1 (and k2 if l2 > 0)
     if (!ws || (!h1 && !k1) || (h1 && !h2) || (k1 && l.l2 > 0 && !k2)) return V2VAE_EINVAL;
-    hipLaunchKernelGGL(k_prep_tables, dim3(16), dim3(NT), 0, (hipStream_t)stream, l, h1, h2, k1, k2, (float*)ws);
-    if (k1 && l.eqcxb_fwd) launch_prep_eqcxb(l, k1, k2, (float*)ws, (hipStream_t)stream);
+    if (k1 && l.eqcxb_fwd) {
+        hipLaunchKernelGGL(k_prep_tables_eq, dim3(16 + PREP_EQCXB_BLOCKS), dim3(NT), 0, (hipStream_t)stream, l, h1, h2, k1, k2,
+                           (float*)ws, 16);
+    } else {
+        hipLaunchKernelGGL(k_prep_tables, dim3(16), dim3(NT), 0, (hipStream_t)stream, l, h1, h2, k1, k2, (float*)ws);
+    }
     if (k1 && l.eqsymr) launch_prep_eqsymr(l, k1, k2, (float*)ws, (hipStream_t)stream);
     if (h1 && l.use_cxb) launch_prep_cxb(l, h1, h2, (float*)ws, (hipStream_t)stream);
     return launch_status();
@@ -2023,6 +2037,15 @@ int v2vae_eq_bwd(const v2vae_problem* p, const float* y, const float* gxhat, voi
     return launch_status();
 }
 
+// both chain rules of the matrix-core paths in one launch: workgroups [0, nb_ch) the channel kernels, the rest the equaliser's
+__global__ __launch_bounds__(NT) void k_chain_both_cx(Lay l, const float* __restrict__ ws, const double* __restrict__ scal,
+                                                      const float* __restrict__ grad_scale, float* __restrict__ g_h1,
+                                                      float* __restrict__ g_h2, float* __restrict__ g_k1, float* __restrict__ g_k2,
+                                                      int nb_ch) {
+    if ((int)blockIdx.x < nb_ch) d_chain_channel_cx(l, ws, scal, grad_scale, g_h1, g_h2, (int)blockIdx.x, nb_ch);
+    else d_chain_equaliser_cx(l, ws, g_k1, g_k2, (int)blockIdx.x - nb_ch, (int)gridDim.x - nb_ch);
+}
+
 int v2vae_finish_grads(const v2vae_problem* p, void* ws, const double* scal, const float* grad_scale, int which,
                        float* g_h1, float* g_h2, float* g_k1, float* g_k2, float* g_scaling, void* stream) {
     Lay l;
@@ -2042,6 +2065,13 @@ int v2vae_finish_grads(const v2vae_problem* p, void* ws, const double* scal, con
     else if ((which & 4) && l.use_eqcxb) sum_sets_add(ss, w + l.o_part_eqcxb, l.eqcxb_rec, l.nblk_eq, stage + 2 * l.sumstage_stride, w + l.o_tot_eqcxb);
     else if (which & 4) sum_sets_add(ss, w + l.o_part_eq, l.rec_eq, l.nblk_eq, stage + 2 * l.sumstage_stride, w + l.o_tot_eq);
     sum_sets_launch(ss, st);
+    if ((which & 1) && l.use_cx && (which & 4) && l.eqb16) {
+        const int n_ch = (l.cx_real ? 1 : 2) * (l.L + l.L * l.L), n_eq = l.ns * (l.l1 + l.l2 * l.l2);
+        const int nb_ch = (n_ch + NT - 1) / NT, nb_eq = (n_eq + NT - 1) / NT;
+        hipLaunchKernelGGL(k_chain_both_cx, dim3(nb_ch + nb_eq), dim3(NT), 0, st, l, (const float*)w, scal, grad_scale, g_h1, g_h2,
+                           g_k1, g_k2, nb_ch);
+        return launch_status();
+    }
     if ((which & 1) && l.use_cx) {
         launch_chain_channel_cx(l, w, scal, grad_scale, g_h1, g_h2, st);
     } else if ((which & 1) && l.use_cxb) {

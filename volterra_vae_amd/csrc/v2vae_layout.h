@@ -114,7 +114,6 @@ struct Lay {
 V2VAE_HD inline int rec_elbo_phase(const Lay& l) { return l.ns * l.LTp * l.LTp + l.LTp * l.LTp + l.ns * 3 * l.LTp; }
 
 int make_layout(const v2vae_problem* p, Lay* out);
-int launch_prep_eqcxb(const Lay& l, const float* k1, const float* k2, float* ws, hipStream_t st);
 int launch_eq_fwd_cxb(const Lay& l, const float* y, const float* ws, float* xhat, hipStream_t st);
 int launch_prep_eqsymr(const Lay& l, const float* k1, const float* k2, float* ws, hipStream_t st);
 int launch_eq_fwd_symr(const Lay& l, const float* y, float* ws, float* xhat, hipStream_t st);
