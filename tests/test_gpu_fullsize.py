@@ -1,5 +1,5 @@
 """Size-independent properties at the size of the headline benchmark (complex 16-QAM, L = l1 = l2 = 25, 2^22 symbols; far
-beyond what the CPU oracle finishes): (1) E, the KL term and every gradient are sums over windows / symbols, so the two halo
+beyond what the CPU oracle finishes) and, for the first, of the long-channel 64-QAM shape (L = l1 = l2 = 65): (1) E, the KL term and every gradient are sums over windows / symbols, so the two halo
 shards of the batch, each evaluated by the kernels with non-zero range offsets, must add up to the whole batch; (2) the
 matrix-core kernels against the generic FMA kernels (the ones the reference's goldens pin) on the same 2^22 symbols."""
 import numpy as np
@@ -8,7 +8,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-L, S, l1, l2, M, LOG2B = 25, 2, 25, 25, 4, 22
+HEADLINE = (25, 2, 25, 25, 4, 22)      # L, S, l1, l2, levels per axis, log2(symbols)
+LONG_CHANNEL = (65, 2, 65, 65, 8, 22)  # the 64-QAM shape of the 8-GPU configuration (blocked matrix-core kernels)
 
 
 def rel(a, b):
@@ -17,20 +18,21 @@ def rel(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-300))
 
 
-def _setup():
+def _setup(shape, ns=2):
     from volterra_vae_amd.synth_device import nonlinear_isi_device
+    L, S, l1, l2, M, LOG2B = shape
     B = 1 << LOG2B
     lv1 = np.arange(-(M - 1), M, 2)
-    y = nonlinear_isi_device(4242, lv1, 2, S, 16.0, B, 0, B, device="cuda").contiguous()
+    y = nonlinear_isi_device(4242, lv1, ns, S, 16.0, B, 0, B, device="cuda").contiguous()
     g = torch.Generator().manual_seed(11)
-    n = [2 * L, 2 * L * L, 2 * l1, 2 * l2 * l2, 2 * M]
+    n = [ns * L, ns * L * L, ns * l1, ns * l2 * l2, ns * M]
     o = np.cumsum([0] + n)
     params = (0.01 * torch.randn(sum(n), generator=g)).cuda()
     params[L // 2] += 1.0
     params[o[2] + l1 // 2] += 1.0
     params[o[4]:] = 1.0 + 0.1 * torch.rand(n[4], generator=g).cuda()
     lv = torch.tensor(lv1, dtype=torch.float32, device="cuda")
-    levels = torch.stack((lv, lv)).contiguous()
+    levels = torch.stack([lv] * ns).contiguous()
     prior = torch.full_like(levels, 1.0 / M)
     nv = torch.tensor([0.04], device="cuda")
     return B, y, params, o, levels, prior, nv
@@ -38,7 +40,7 @@ def _setup():
 
 def _forward(plan, y, params, o, levels, prior, nv):
     h1, h2, k1, k2, sc = (params[o[i]:o[i + 1]] for i in range(5))
-    xhat = torch.empty((2, plan.p.sym_cnt), dtype=torch.float32, device="cuda")
+    xhat = torch.empty((plan.p.ns, plan.p.sym_cnt), dtype=torch.float32, device="cuda")
     plan.prep_tables(h1, h2, k1, k2)
     plan.eq_fwd(y, xhat)
     plan.demap_moments(xhat, levels, prior, sc, nv)
@@ -58,11 +60,13 @@ def _backward(plan, y, xhat, params, o, levels, prior, nv):
     return g
 
 
-def test_halo_shards_of_the_headline_batch_add_up_to_the_whole_batch():
+@pytest.mark.parametrize("shape", [HEADLINE, LONG_CHANNEL])
+def test_halo_shards_of_a_full_size_batch_add_up_to_the_whole_batch(shape):
     from volterra_vae_amd import _lib
     from volterra_vae_amd.distributed import shard_ranges
     from volterra_vae_amd.ops import Plan
-    B, y, params, o, levels, prior, nv = _setup()
+    L, S, l1, l2, M, LOG2B = shape
+    B, y, params, o, levels, prior, nv = _setup(shape)
     kw = dict(ns=2, sps=S, l1=l1, pad1=l1 // 2, l2=l2, L=L, C_levels=M, n_glob=B * S, device="cuda")
     whole = Plan(**kw)
     xw = _forward(whole, y, params, o, levels, prior, nv)
@@ -98,13 +102,16 @@ def test_halo_shards_of_the_headline_batch_add_up_to_the_whole_batch():
         assert e < 2e-6, (name, e)   # float32 partial sums in another grouping
 
 
-def test_matrix_core_kernels_agree_with_the_generic_kernels_at_the_headline_size():
+@pytest.mark.parametrize("ns", [2, 1])
+def test_matrix_core_kernels_agree_with_the_generic_kernels_at_the_headline_size(ns):
+    """ns = 1: the real PAM-4 model on the same kernels (zero quadrature stream), against the generic real kernels."""
     from volterra_vae_amd import _lib
     from volterra_vae_amd.ops import Plan
-    B, y, params, o, levels, prior, nv = _setup()
+    L, S, l1, l2, M, LOG2B = HEADLINE
+    B, y, params, o, levels, prior, nv = _setup(HEADLINE, ns)
     res = []
     for flags in (0, _lib.FLAG_GENERIC):
-        plan = Plan(ns=2, sps=S, l1=l1, pad1=l1 // 2, l2=l2, L=L, C_levels=M, n_glob=B * S, device="cuda", flags=flags)
+        plan = Plan(ns=ns, sps=S, l1=l1, pad1=l1 // 2, l2=l2, L=L, C_levels=M, n_glob=B * S, device="cuda", flags=flags)
         xh = _forward(plan, y, params, o, levels, prior, nv)
         g = _backward(plan, y, xh, params, o, levels, prior, nv)
         res.append((float(plan.scal[_lib.SCAL_E]), float(plan.scal[_lib.SCAL_KL]), float(plan.scal[_lib.SCAL_LOSS]), xh.clone(), g))
