@@ -123,3 +123,24 @@ def test_matrix_core_kernels_agree_with_the_generic_kernels_at_the_headline_size
         e = rel(g0[o[i]:o[i + 1]], g1[o[i]:o[i + 1]])
         print(f"2^{LOG2B} symbols, gradient of {name}: matrix-core against generic kernels {e:.2e}")
         assert e < 1e-5, (name, e)
+
+
+@pytest.mark.parametrize("shape", [HEADLINE, LONG_CHANNEL])
+def test_full_size_step_is_bitwise_reproducible(shape):
+    """Every sum of the path has a fixed order (per-workgroup records, two-stage record sums, no floating-point atomics): the
+    same inputs give the same bits, on a fresh workspace and on one that has been used."""
+    from volterra_vae_amd import _lib
+    from volterra_vae_amd.ops import Plan
+    L, S, l1, l2, M, LOG2B = shape
+    B, y, params, o, levels, prior, nv = _setup(shape)
+    kw = dict(ns=2, sps=S, l1=l1, pad1=l1 // 2, l2=l2, L=L, C_levels=M, n_glob=B * S, device="cuda")
+    runs = []
+    plan = Plan(**kw)
+    for rep in range(3):
+        if rep == 2:
+            plan = Plan(**kw)   # fresh workspace
+        xh = _forward(plan, y, params, o, levels, prior, nv)
+        g = _backward(plan, y, xh, params, o, levels, prior, nv)
+        runs.append((plan.scal.clone(), xh.clone(), g.clone()))
+    for sc, xh, g in runs[1:]:
+        assert torch.equal(sc, runs[0][0]) and torch.equal(xh, runs[0][1]) and torch.equal(g, runs[0][2])
