@@ -230,7 +230,9 @@ def _complex_inputs(seed, L, S, l1, l2, B, M):
 
 @pytest.mark.parametrize("L,S,l1,l2,B,M", [(7, 2, 5, 3, 300, 4), (6, 1, 3, 0, 257, 2), (9, 3, 7, 5, 600, 4),
                                            (25, 2, 25, 25, 1500, 4), (15, 2, 11, 9, 4000, 8), (5, 1, 1, 1, 70, 2),
-                                           (4, 2, 1, 3, 513, 2), (31, 2, 31, 31, 1025, 4)])
+                                           (4, 2, 1, 3, 513, 2), (31, 2, 31, 31, 1025, 4),
+                                           # the largest level count (256-QAM) and sample counts per symbol up to the limit of 8
+                                           (13, 2, 7, 5, 500, 16), (9, 4, 5, 3, 300, 4), (17, 8, 9, 5, 200, 2)])
 def test_complex_step_matches_oracle(L, S, l1, l2, B, M):
     from oracle import v2vae_oracle as orc
     from volterra_vae_amd.ops import Plan
