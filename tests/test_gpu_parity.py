@@ -403,3 +403,52 @@ def test_hard_decisions_equal_argmax_of_posteriors(ns, M, B):
     qa = torch.argmax(q, dim=1).cpu().numpy()
     agree = (d == qa).mean()
     assert agree > 1 - 1e-4, agree
+
+
+@pytest.mark.parametrize("L,S,l1,l2,B,M", [(9, 2, 7, 5, 400, 16), (11, 4, 9, 5, 300, 8), (17, 8, 5, 3, 150, 2),
+                                           (15, 2, 63, 61, 700, 4), (7, 1, 3, 129, 600, 4), (6, 3, 255, 0, 500, 4)])
+def test_real_step_at_the_limits_of_the_parameter_ranges_matches_oracle(L, S, l1, l2, B, M):
+    """Real model where the reference's goldens do not reach: PAM-16 / PAM-8 (the 16- and 8-level instantiations), 4 and 8
+    samples per symbol, equalisers of 63 / 61 lags, the longest second-order (129 lags) and first-order (255 taps) kernels, an
+    even channel memory.  Checked against the fp64 oracle (itself pinned to the reference's fp64 goldens to 1e-11) evaluated on
+    the float32-rounded inputs."""
+    from oracle import v2vae_oracle as orc
+    from volterra_vae_amd.ops import Plan
+    from volterra_vae_amd.synth import nonlinear_isi, pam_constellation
+    rng = np.random.default_rng(31)
+    rx, _ = nonlinear_isi(B, pam_constellation(M), S, 18.0, rng)
+    f32 = lambda a: np.asarray(a, dtype=np.float32)
+    y = f32(np.real(rx))
+    lv = f32(np.arange(-(M - 1), M, 2))
+    h1 = 0.05 * rng.standard_normal(L); h1[L // 2] += 1.0
+    h2 = 0.01 * rng.standard_normal((L, L))
+    k1 = 0.02 * rng.standard_normal(l1); k1[l1 // 2] += 1.0
+    k2 = 0.003 * rng.standard_normal((l2, l2)) / max(l2, 1) ** 0.5 if l2 else None
+    sc = 1.0 + 0.2 * rng.random(M)
+    h1, h2, k1, sc = f32(h1), f32(h2), f32(k1), f32(sc)
+    k2 = None if k2 is None else f32(k2)
+    nvf = np.float32(0.15)
+    t = lambda a: torch.from_numpy(a.astype(np.float64))
+    th1, th2, tk1, tsc = (t(a).requires_grad_() for a in (h1, h2, k1, sc))
+    tk2 = None if k2 is None else t(k2).requires_grad_()
+    ty, tlv = t(y), t(lv)
+    prior = torch.ones_like(tlv) / M
+    nv = torch.tensor(float(nvf), dtype=torch.float64)
+    xr = orc.fir_equaliser(ty, tk1, S) if k2 is None else orc.volterra_equaliser(ty, tk1, tk2, S)
+    loss, E, _ = orc.elbo_reference_form(xr, ty, th1, th2, tlv, prior, nv, tsc, S)
+    loss.backward()
+    lin = k2 is None
+    plan = Plan(ns=1, sps=S, l1=l1, pad1=(l1 - 1) // 2 if lin else l1 // 2, l2=l2, L=L, C_levels=M, n_glob=B * S, device="cuda")
+    out = run_step(plan, dev(y[None, :]), dev(h1), dev(h2), dev(k1), None if lin else dev(k2), dev(lv[None, :]),
+                   dev(np.ones((1, M)) / M), dev(sc[None, :]), dev(np.array([nvf])))
+    assert rel(out["xhat"][0], xr.detach().numpy()) < TOL_EXACT
+    loss_ref, e_ref = float(loss.detach()), float(E.detach())
+    assert abs(out["loss"] - loss_ref) < TOL_EXACT * abs(loss_ref)
+    assert abs(out["E"] - e_ref) < TOL_EXACT * abs(e_ref)
+    for key, ours, ref in (("h1", out["g"]["h1"], th1.grad), ("h2", out["g"]["h2"], th2.grad), ("k1", out["g"]["k1"], tk1.grad),
+                           ("noise scaling", out["g"]["sc"][0], tsc.grad)):
+        e = rel(ours, ref.numpy())
+        print(f"L={L} S={S} l1={l1} l2={l2} M={M} gradient of {key}: {e:.2e}")
+        assert e < TOL, (key, e)
+    if not lin:
+        assert rel(out["g"]["k2"], tk2.grad.numpy()) < TOL
