@@ -21,7 +21,7 @@ def rel(a, b):
 def _setup(shape, ns=2):
     from volterra_vae_amd.synth_device import nonlinear_isi_device
     L, S, l1, l2, M, LOG2B = shape
-    B = 1 << LOG2B
+    B = LOG2B if LOG2B > 64 else 1 << LOG2B   # the last entry of a shape: log2 of the symbol count, or the count itself
     lv1 = np.arange(-(M - 1), M, 2)
     y = nonlinear_isi_device(4242, lv1, ns, S, 16.0, B, 0, B, device="cuda").contiguous()
     g = torch.Generator().manual_seed(11)
@@ -60,8 +60,9 @@ def _backward(plan, y, xhat, params, o, levels, prior, nv):
     return g
 
 
-@pytest.mark.parametrize("shape", [HEADLINE, LONG_CHANNEL])
-def test_halo_shards_of_a_full_size_batch_add_up_to_the_whole_batch(shape):
+@pytest.mark.parametrize("shape,world", [(HEADLINE, 2), (LONG_CHANNEL, 2), ((25, 2, 25, 25, 4, 100003), 3),
+                                         ((47, 1, 31, 31, 8, 50021), 5), ((25, 2, 25, 25, 4, 1 << 20), 8)])
+def test_halo_shards_of_a_full_size_batch_add_up_to_the_whole_batch(shape, world):
     from volterra_vae_amd import _lib
     from volterra_vae_amd.distributed import shard_ranges
     from volterra_vae_amd.ops import Plan
@@ -76,8 +77,8 @@ def test_halo_shards_of_a_full_size_batch_add_up_to_the_whole_batch(shape):
     loss_whole = float(whole.scal[_lib.SCAL_LOSS])
 
     shards = []
-    for rank in range(2):
-        sr = shard_ranges(rank, 2, B * S, S, L, l1, l1 // 2, l2)
+    for rank in range(world):   # uneven shares when the symbol count is not a multiple of the number of ranks
+        sr = shard_ranges(rank, world, B * S, S, L, l1, l1 // 2, l2)
         plan = Plan(y_lo=sr.y_lo, y_len=sr.y_len, sym_lo=sr.sym_lo, sym_cnt=sr.sym_cnt, own_lo=sr.own_lo, own_cnt=sr.own_cnt, **kw)
         ys = y[:, sr.y_lo:sr.y_lo + sr.y_len].contiguous()
         xs = _forward(plan, ys, params, o, levels, prior, nv)
@@ -98,7 +99,7 @@ def test_halo_shards_of_a_full_size_batch_add_up_to_the_whole_batch(shape):
         assert torch.equal(xs[:, a:a + sr.own_cnt], xw[:, sr.own_lo:sr.own_lo + sr.own_cnt])   # same samples, same arithmetic
     for name, i in (("h1", 0), ("h2", 1), ("k1", 2), ("k2", 3), ("noise scaling", 4)):
         e = rel(g_sum[o[i]:o[i + 1]], gw[o[i]:o[i + 1]])
-        print(f"2^{LOG2B} symbols, gradient of {name}: two shards against the whole batch {e:.2e}")
+        print(f"{B} symbols, gradient of {name}: {world} shards against the whole batch {e:.2e}")
         assert e < 2e-6, (name, e)   # float32 partial sums in another grouping
 
 
