@@ -156,8 +156,8 @@ def sweep_main(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--log2-symbols", type=int, default=22, help="symbols per GPU = 2^this")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--channel-memory", type=int, default=25, help="L (65 with --order 64 = BASELINE.json configs[3] per GPU)")
