@@ -74,6 +74,7 @@ def sweep_main(args):
     mini-batch training step of every model; the timed region is ONE launch of --steps batches per rank."""
     import torch
     import torch.distributed as dist
+    from volterra_vae_amd.distributed import all_reduce_small
     from volterra_vae_amd.sweep import SecondVolterraV2VAESweep, shard_models
     from volterra_vae_amd.synth import nonlinear_isi, pam_constellation
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -127,7 +128,7 @@ def sweep_main(args):
     kernel_ms = e0.elapsed_time(e1)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce_small(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     if not bool(torch.isfinite(lc).all()):
         raise SystemExit("non-finite loss in the sweep")
@@ -158,7 +159,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--log2-symbols", type=int, default=22, help="symbols per GPU = 2^this")
+    ap.add_argument("--log2-symbols", type=int, default=None,
+                    help="symbols per GPU = 2^this (default 22; 23 with --workload cfg4; ignored by --workload sweep)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--channel-memory", type=int, default=25, help="L (65 with --order 64 = BASELINE.json configs[3] per GPU)")
     ap.add_argument("--lags", type=int, default=25, help="equaliser lags l1 = l2")
@@ -178,11 +180,13 @@ def main():
     if args.workload == "sweep":
         return sweep_main(args)
     if args.workload == "cfg4":
-        args.channel_memory, args.lags, args.order, args.log2_symbols, args.data_source = 65, 65, 64, 23, "device"
+        args.channel_memory, args.lags, args.order, args.data_source = 65, 65, 64, "device"
+    if args.log2_symbols is None:
+        args.log2_symbols = 23 if args.workload == "cfg4" else 22
 
     import torch
     import torch.distributed as dist
-    from volterra_vae_amd.distributed import ShardedTrainer, shard_ranges
+    from volterra_vae_amd.distributed import ShardedTrainer, all_reduce_small, shard_ranges
     from volterra_vae_amd.ops import Plan
     from volterra_vae_amd.synth import nonlinear_isi_range, qam_constellation
 
@@ -261,7 +265,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce_small(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     final_loss = float(loss)
     if not np.isfinite(final_loss):

@@ -117,3 +117,35 @@ def test_two_rank_gloo_step_equals_unsharded_step():
         assert p.exitcode == 0
     assert abs(loss - ref["loss"]) < 1e-10 * abs(ref["loss"])
     assert np.linalg.norm(flat - ref_flat) < 1e-9 * np.linalg.norm(ref_flat)
+
+
+def _rank_small_allreduce(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    from volterra_vae_amd.distributed import all_reduce_small, collectives_need_host_staging
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    t = torch.tensor([1.0 + rank, 10.0 * (rank + 1)], dtype=torch.float64)
+    all_reduce_small(t[:2])
+    m = torch.tensor([float(rank)])
+    all_reduce_small(m, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        out.put((t.tolist(), float(m), collectives_need_host_staging()))
+    dist.destroy_process_group()
+
+
+def test_small_all_reduce_over_gloo_two_ranks():
+    """The helper the sharded step and bench.py reduce their payloads with: sum and max over two gloo ranks, and gloo is
+    reported as a backend whose device tensors are staged through host memory."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_rank_small_allreduce, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    total, mx, staged = out.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert total == [3.0, 30.0] and mx == 1.0 and staged is True

@@ -50,6 +50,34 @@ def shard_ranges(rank: int, world: int, n_glob: int, sps: int, L: int, l1: int, 
     return ShardRanges(own_lo, own_cnt, sym_lo, sym_hi - sym_lo, y_lo, y_hi - y_lo)
 
 
+def collectives_need_host_staging(group=None) -> bool:
+    """True when the group's backend has no device collectives (gloo: rehearsals of the multi-rank path with several
+    ranks on one GPU, CPU tests).  RCCL ("nccl") reduces device tensors on the compute stream and needs none."""
+    import torch.distributed as dist
+    return dist.get_backend(group) != "nccl"
+
+
+def all_reduce_small(t, group=None, op=None, host_staged=None):
+    """In-place all-reduce of a small tensor (the step's payloads are 2 doubles and the <= 34 KB gradient pack).
+
+    Over RCCL the device tensor is reduced as it is.  Over gloo a device tensor goes through host memory explicitly: copy to
+    the host (which waits for the kernels queued before it), gloo on host memory, copy back.  gloo's own handling of device
+    tensors (a pinned staging copy on a side stream that waits for an event of the compute stream, synchronised from a worker
+    thread) stalls intermittently on this stack when about a millisecond of kernels is queued in front of it and two
+    processes share the GPU - with torch kernels alone as well as with this library's (tools/gloo_cuda_repro.py,
+    tools/rehearse_shard.py) - so it is not used."""
+    import torch.distributed as dist
+    op = dist.ReduceOp.SUM if op is None else op
+    if host_staged is None:
+        host_staged = collectives_need_host_staging(group)
+    if host_staged and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+
+
 class ShardedTrainer:
     """One data-parallel V2VAE training step over a halo-sharded batch.
 
@@ -61,6 +89,7 @@ class ShardedTrainer:
         self.plan = plan
         self.dist = dist
         self.group = process_group
+        self.host_staged = collectives_need_host_staging(process_group)
 
     def step(self, *, accumulate_scaling_grad=False, **kw):
         """Keyword arguments as for Plan.train_args (y, levels, prior, params, grads, adam_m, adam_v, adam_vmax, noise_var,
@@ -72,7 +101,7 @@ class ShardedTrainer:
         plan, dist = self.plan, self.dist
         a = plan.train_args(**kw)
         plan.sharded_pre(a)
-        dist.all_reduce(plan.scal[:2], group=self.group)
+        all_reduce_small(plan.scal[:2], self.group, host_staged=self.host_staged)
         plan.sharded_post(a)
-        dist.all_reduce(kw["grads"], group=self.group)
+        all_reduce_small(kw["grads"], self.group, host_staged=self.host_staged)
         plan.update(a)
