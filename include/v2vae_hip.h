@@ -213,7 +213,10 @@ int v2vae_train_step_update(const v2vae_problem* p, const v2vae_train_args* a, v
  * results are bit-identical to it.  Calls no hipMalloc / hipFree or any other allocating routine.  V2VAE_ESIZE (and a
  * v2vae_last_error text with both sizes) if v2vae_static_scratch_bytes(p) exceeds the array.  All calls on one GPU share that
  * GPU's array: it is cleared at the start of every call, and two calls that overlap in time on one GPU (different streams or
- * threads) race - serialise them. */
+ * threads) race - serialise them.  The stream must belong to the calling thread's current device (V2VAE_EINVAL otherwise).
+ * The first call on a device resolves the array's address (hipGetSymbolAddress, which may load the code object): make it
+ * outside a graph capture.  Adam's bias corrections and the learning rate are computed on the host from a->step and a->lr and
+ * travel as kernel arguments, so a captured step replays with the step count and rate it was captured with. */
 #define V2VAE_STATIC_SCRATCH_BYTES (32u << 20)
 size_t v2vae_static_scratch_bytes(const v2vae_problem* p); /* bytes of the array this problem would use; 0 if invalid */
 int v2vae_train_step_static(const v2vae_problem* p, const v2vae_train_args* a, void* stream);
@@ -312,6 +315,15 @@ uint64_t v2vae_synth_bits(uint64_t seed, uint64_t kind, uint64_t idx);
  * backward their gradients in a layout of their own. */
 int64_t v2vae_ws_offset_moments(const v2vae_problem* p);
 int64_t v2vae_ws_offset_gmoments(const v2vae_problem* p);
+
+/* Real models (one stream): float offsets of the two workspace planes [sym_cnt] in which v2vae_eq_fwd keeps its output as a float
+ * (a copy of xhat) and the float remainder of the double-precision sum behind it; -1 when the layout has none.  A caller that
+ * runs the equaliser on one workspace and the soft demapper / per-symbol backward on another (the reference's module structure:
+ * SecondOrderVolterraSeries.forward, lib/torch_components.py:79-96, is a module of its own; _calculate_loss,
+ * lib/real_equalization.py:836-925, belongs to the estimator) copies the two planes across so that the remainder takes effect
+ * there as well. */
+int64_t v2vae_ws_offset_xhat_float(const v2vae_problem* p);
+int64_t v2vae_ws_offset_xhat_remainder(const v2vae_problem* p);
 
 const char* v2vae_version(void);
 

@@ -51,8 +51,12 @@ def test_single_step_against_reference(case, generic, monkeypatch):
     gk = m.equaliser_k1.grad
     g_dec = torch.stack((gk[0], -gk[1])).unsqueeze(0)
     for ours, key in ((g_enc, "g_enc_w"), (g_dec, "g_dec_w")):
+        # 1e-5 against the reference's fp64 run with no allowance; against its fp32 run its own fp32 - fp64 distance is added
         own = rel(g32[key], g64[key])
-        assert rel(ours, g64[key]) < TOL + own, (key, rel(ours, g64[key]), own)
+        e64, e32 = rel(ours, g64[key]), rel(ours, g32[key])
+        print(f"{case} generic={generic} {key}: vs fp64 ref {e64:.2e}, vs fp32 ref {e32:.2e} (ref32-ref64 {own:.2e})")
+        assert e64 < TOL, (key, e64)
+        assert e32 < TOL + own, (key, e32, own)
 
 
 def test_fit_trajectory_against_reference():

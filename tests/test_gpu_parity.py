@@ -340,10 +340,12 @@ def test_complex_long_equaliser_blocked_kernel_matches_oracle(l1, l2, S, B):
     out = run_step(plan, dev(y), dev(h1), dev(h2), dev(k1), dev(k2), dev(levels), dev(prior), dev(scaling), dev(np.array([nv])))
     assert rel(out["xhat"], xr.detach().numpy()) < TOL
     assert abs(out["loss"] - float(loss.detach())) < TOL * abs(float(loss.detach()))
-    # the equaliser gradients see the fp32 rounding of xhat amplified by 2 |xhat - level| / (noise variance * scaling) ~ 20
-    # at this noise level (0.09), on top of their own summation error: twice the base tolerance
-    assert rel(out["g"]["k1"], tk1.grad) < 2 * TOL
-    assert rel(out["g"]["k2"], tk2.grad) < 2 * TOL
+    # (the equaliser gradients see the error of xhat amplified by 2 |xhat - level| / (noise variance * scaling) ~ 20 at this
+    # noise level: the forward's sum over the lag rows runs in double and is rounded to float once)
+    for key, ours, ref in (("k1", out["g"]["k1"], tk1.grad), ("k2", out["g"]["k2"], tk2.grad)):
+        e = rel(ours, ref)
+        print(f"l1={l1} l2={l2} S={S}: gradient of {key} {e:.2e}")
+        assert e < TOL, (key, e)
     assert rel(out["g"]["h1"], th1.grad) < TOL
 
 

@@ -9,7 +9,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
-TOL = 1e-5  # fp32 relative tolerance of the hot path; the reference's own fp32-vs-fp64 distance is added where it dominates
+TOL = 1e-5  # fp32 relative tolerance of the hot path (20-step trajectories add the reference's own fp32-vs-fp64 distance)
 
 
 def rel(a, b):
@@ -68,8 +68,13 @@ def test_single_step_loss_and_gradients(case):
     loss.backward()
 
     def chk(ours, key):
+        # 1e-5 against the reference's fp64 run with no allowance; against its fp32 run the reference's own fp32 - fp64 distance
+        # is added
         own = rel(g32[key], g64[key])
-        assert rel(ours, g64[key]) < TOL + own, (key, rel(ours, g64[key]), own)
+        e64, e32 = rel(ours, g64[key]), rel(ours, g32[key])
+        print(f"{case} {key}: vs fp64 ref {e64:.2e}, vs fp32 ref {e32:.2e} (ref32-ref64 {own:.2e})")
+        assert e64 < TOL, (key, e64)
+        assert e32 < TOL + own, (key, e32, own)
     if kind == "mpvae":
         chk(m.channel_h1.grad, "g_h1")
         chk(m.channel_h2.grad, "g_h2")

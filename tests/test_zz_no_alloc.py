@@ -79,3 +79,25 @@ def test_static_scratch_rejects_a_problem_beyond_the_array():
     a = _lib.TrainArgs()
     a.ws = plan.ws.data_ptr()
     assert _lib.lib.v2vae_train_step_static(C.byref(plan.p), C.byref(a), None) == _lib.EINVAL
+
+
+def test_static_scratch_step_allocates_no_device_memory():
+    """What the entry point exists for: after one warm-up call (address of the array resolved, code object loaded) further
+    calls leave the free device memory and torch's reserved pool exactly where they were."""
+    plan, y, params, levels, prior = _case(**CASES[0])
+    dev = y.device
+    grads, m, v, vm = (torch.zeros_like(params) for _ in range(4))
+    nv = torch.tensor([0.05], dtype=torch.float32, device=dev)
+    xhat = torch.empty((plan.p.ns, plan.p.sym_cnt), dtype=torch.float32, device=dev)
+    loss = torch.zeros(1, dtype=torch.float32, device=dev)
+    kw = dict(y=y, levels=levels, prior=prior, params=params, grads=grads, adam_m=m, adam_v=v, adam_vmax=vm, noise_var=nv,
+              xhat=xhat, loss_out=loss, lr=5e-3, static_scratch=True)
+    plan.train_step(step=1, **kw)
+    torch.cuda.synchronize()
+    free0, reserved0, allocated0 = torch.cuda.mem_get_info()[0], torch.cuda.memory_reserved(), torch.cuda.memory_allocated()
+    for step in range(2, 8):
+        plan.train_step(step=step, **kw)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0
+    assert torch.cuda.memory_reserved() == reserved0 and torch.cuda.memory_allocated() == allocated0
+    assert torch.isfinite(loss).all()

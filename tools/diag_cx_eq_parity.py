@@ -42,6 +42,23 @@ def main():
         nv = 0.09
         plan = Plan(ns=2, sps=S, l1=l1, pad1=l1 // 2, l2=l2, L=L, C_levels=M, n_glob=B * S, device="cuda")
         out = run_step(plan, dev(y), dev(h1), dev(h2), dev(k1), dev(k2), dev(levels), dev(prior), dev(scaling), dev(np.array([nv])))
+        # the same step with the oracle's xhat (rounded to float32: 3e-8 relative) in place of the forward kernel's
+        o32 = oracle(y, levels, prior, scaling, h1, h2, k1, k2, nv, S, True)
+        xin = dev(o32["xhat"])
+        dy, dl, dp, dsc, dnv = dev(y), dev(levels), dev(prior), dev(scaling), dev(np.array([nv]))
+        plan.prep_tables(dev(h1), dev(h2), dev(k1), dev(k2))
+        plan.demap_moments(xin, dl, dp, dsc, dnv)
+        plan.elbo_fused(dy)
+        plan.reduce_scalars()
+        plan.finalize_scalars()
+        gx = plan.sym_bwd(xin, dl, dp, dsc, dnv)
+        plan.eq_bwd(dy, gx)
+        g = dict(h1=torch.empty_like(dev(h1)), h2=torch.empty_like(dev(h2)), k1=torch.empty_like(dev(k1)), k2=torch.empty_like(dev(k2)),
+                 sc=torch.empty_like(dsc))
+        plan.finish_grads(7, g["h1"], g["h2"], g["k1"], g["k2"], g["sc"])
+        torch.cuda.synchronize()
+        print(f"l1={l1} l2={l2} S={S} B={B} oracle xhat injected:           " +
+              "  ".join(f"g_{k} {rel(g[k], o32[k]):.2e}" for k in ("h1", "h2", "k1", "k2", "sc")), flush=True)
         for tag, r32 in (("f64 inputs", False), ("f32-rounded inputs", True)):
             o = oracle(y, levels, prior, scaling, h1, h2, k1, k2, nv, S, r32)
             line = [f"xhat {rel(out['xhat'], o['xhat']):.2e}", f"loss {abs(out['loss'] - o['loss']) / abs(o['loss']):.2e}"]

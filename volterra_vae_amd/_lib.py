@@ -111,6 +111,8 @@ EXPORTS = {
     "v2vae_fit_persistent_kind": (C.c_int, [C.POINTER(Problem)]),
     "v2vae_ws_offset_moments": (C.c_int64, [C.POINTER(Problem)]),
     "v2vae_ws_offset_gmoments": (C.c_int64, [C.POINTER(Problem)]),
+    "v2vae_ws_offset_xhat_float": (C.c_int64, [C.POINTER(Problem)]),
+    "v2vae_ws_offset_xhat_remainder": (C.c_int64, [C.POINTER(Problem)]),
 }
 
 

@@ -1,7 +1,7 @@
 // Complex second-order Volterra equaliser.  Two forward kernels and the backward for the longest kernels:
-//  * k_eq_fwd_sym<T>: the forward in symmetric form on the vector pipe, up to 65 lags (the default; described at the kernel);
-//  * k_eq_fwd_cxb<NBL> / k_eq_bwd_cxb<NBL>: the f32 matrix cores with the lag rows in NBL blocks of 32: forward for 67 .. 95
-//    lags (and, on request, for any length up to 95: the A/B switch of the symmetric form), backward for 81 .. 95 lags
+//  * k_eq_fwd_sym<T>: the forward in symmetric form on the vector pipe, up to 95 lags (the default; described at the kernel);
+//  * k_eq_fwd_cxb<NBL> / k_eq_bwd_cxb<NBL>: the f32 matrix cores with the lag rows in NBL blocks of 32: forward on request
+//    (V2VAE_FLAG_EQ_MFMA_FWD, the A/B switch of the symmetric form), backward for 81 .. 95 lags
 //    (v2vae_eq_cx.hip has the backward on 16-lag blocks up to 79 lags).
 //
 // xhat_b = sum_j k1[j] y[bS + j - p1] + Y_b^T K Y_b,  K = k2 + k2^T complex symmetric, Y_b[x] = y[bS + p2 - x]
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(NT) void k_chain_equaliser_cxb(Lay l, const float* 
     }
 }
 
-// Forward equaliser in symmetric form on the vector pipe, for kernels of up to 65 lags (instances 9, 17, 25, 31, 47, 65):
+// Forward equaliser in symmetric form on the vector pipe, for kernels of up to 95 lags (instances 9, 17, 25, 31, 47, 65, 79, 95):
 //   xhat = sum_a y_a (k1w_a + sum_{b >= a} K'_ab y_b),  K'_ab = K_ab (a = b), 2 K_ab (a < b),  y_x = y[b S + p2 - x],
 // T (T + 1) / 2 + T complex multiply-adds per symbol instead of the T^2 of the matrix product (the f32 matrix rate equals the
 // packed vector rate on this part, so half the multiply-adds and no padding of the lag count to 32 is what counts).  One
@@ -294,8 +294,20 @@ __device__ __forceinline__ void eq_cmac_v(eq_f2& acc, eq_f2 k, eq_f2 y) {
         : "+v"(acc) : "v"(k), "v"(y));
 }
 
+// End of a row of the symmetric form: u += w (the first-order weight, a scalar pair as loaded), t = u * y (packed complex
+// product, one rounding per component), then (outr + i outi) += t in double.
+__device__ __forceinline__ void eq_row_close(double& outr, double& outi, eq_f2 u, unsigned long long w, eq_f2 y) {
+    eq_f2 t;
+    asm("v_pk_add_f32 %1, %1, %2\n\t"
+        "v_pk_mul_f32 %0, %1, %3 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=&v"(t), "+v"(u) : "s"(w), "v"(y));
+    outr += (double)t.x;
+    outi += (double)t.y;
+}
+
 template <int T>
-__global__ __launch_bounds__(NT, T <= 25 ? 4 : 3) void k_eq_fwd_sym(Lay l, const float* __restrict__ y,
+__global__ __launch_bounds__(NT, T <= 25 ? 4 : T <= 65 ? 3 : 2) void k_eq_fwd_sym(Lay l, const float* __restrict__ y,
                                                                               const float* __restrict__ ws, float* __restrict__ xhat) {
     extern __shared__ float sm[];
     float* tile = sm;
@@ -357,34 +369,41 @@ __global__ __launch_bounds__(NT, T <= 25 ? 4 : 3) void k_eq_fwd_sym(Lay l, const
 #pragma unroll
             for (int x = 0; x < T; ++x) yv[n][x] = reinterpret_cast<const eq_f2*>(tile)[base - x];
         }
-        eq_f2 out[NSY], u[NSY];
+        // The row sums u_a = sum_{b >= a} K'_ab y_b (small terms) are formed in packed float arithmetic, the first-order weight is
+        // added to a finished row sum and the row's product with y_a is formed in float (one rounding each at the size of the
+        // term), and the outer sum over the rows - whose partial sums are of the size of the result from the dominant
+        // first-order tap on - runs in double, rounded to float once at the end: the soft demapper amplifies an error of xhat by 2 |xhat - a| / noise variance on its way into the equaliser
+        // gradients, and a float accumulation over the rows alone left 2 - 4e-7 of relative error in xhat.
+        double outr[NSY], outi[NSY];
+        eq_f2 u[NSY];
 #pragma unroll
-        for (int n = 0; n < NSY; ++n) { out[n] = eq_f2{0.f, 0.f}; u[n] = out[n]; }
+        for (int n = 0; n < NSY; ++n) { outr[n] = 0.0; outi[n] = 0.0; }
         // the table is one stream of entries, fetched eight at a time (one 64-byte scalar load, one wait per eight entries)
         // wherever the flat index crosses a multiple of eight; all indices are compile-time constants after unrolling
         eq_k8 kk;
 #pragma unroll
         for (int a = 0; a < T; ++a) {
-            const int off = a * (T + 1) - a * (a - 1) / 2;   // flat index of the first-order weight that opens row a
-            if ((off & 7) == 0) kk = *reinterpret_cast<const eq_k8 __attribute__((address_space(4)))*>(tab + off);
+            const int off = a * (T + 1) - a * (a - 1) / 2;   // flat index of K'_aa, which opens row a; the first-order weight closes it
 #pragma unroll
-            for (int n = 0; n < NSY; ++n) u[n] = __builtin_bit_cast(eq_f2, (unsigned long long)kk[off & 7]);
+            for (int n = 0; n < NSY; ++n) u[n] = eq_f2{0.f, 0.f};
 #pragma unroll
             for (int b = a; b < T; ++b) {
-                const int idx = off + 1 + (b - a);
+                const int idx = off + (b - a);
                 if ((idx & 7) == 0) kk = *reinterpret_cast<const eq_k8 __attribute__((address_space(4)))*>(tab + idx);
 #pragma unroll
                 for (int n = 0; n < NSY; ++n) eq_cmac_s(u[n], kk[idx & 7], yv[n][b]);
             }
+            const int iw = off + (T - a);
+            if ((iw & 7) == 0) kk = *reinterpret_cast<const eq_k8 __attribute__((address_space(4)))*>(tab + iw);
 #pragma unroll
-            for (int n = 0; n < NSY; ++n) eq_cmac_v(out[n], u[n], yv[n][a]);
+            for (int n = 0; n < NSY; ++n) eq_row_close(outr[n], outi[n], u[n], kk[iw & 7], yv[n][a]);
         }
 #pragma unroll
         for (int n = 0; n < NSY; ++n) {
             const int64_t b = b0 + tid + n * EQ_TB;
             if (b < sym_hi) {
-                xhat[b - l.sym_lo] = out[n].x;
-                xhat[l.sym_cnt + (b - l.sym_lo)] = out[n].y;
+                xhat[b - l.sym_lo] = (float)outr[n];
+                xhat[l.sym_cnt + (b - l.sym_lo)] = (float)outi[n];
             }
         }
     }
@@ -392,7 +411,7 @@ __global__ __launch_bounds__(NT, T <= 25 ? 4 : 3) void k_eq_fwd_sym(Lay l, const
 
 // The REAL model's forward in the same symmetric form, with every sum in double (v_fma_f64 issues at the rate of an unpacked f32
 // FMA on this part): xhat = sum_a y_a (k1w_a + sum_{b >= a} K'_ab y_b) - T (T + 1) / 2 + T multiply-adds per symbol against the
-// T^2 of the generic kernel, samples in registers as doubles, table entries (doubles, same row-interleaved stream as above) by
+// T^2 of the generic kernel, samples in registers as doubles, table entries (doubles; one row-interleaved stream, here with the first-order weight opening its row) by
 // scalar loads, eight per load.  The result leaves as a float plus its float remainder (planes o_xhi / o_xlo), exactly like the
 // generic real forward: the soft demapper amplifies an error of xhat by 2 |xhat - a| / noise variance.
 typedef double eq_d8 __attribute__((ext_vector_type(8)));
@@ -551,7 +570,7 @@ static int eqcxb_allow_lds(K kernel, int bytes) {
 int launch_eq_fwd_cxb(const Lay& l, const float* y, const float* ws, float* xhat, hipStream_t st) {
     int nblk = (int)((l.sym_cnt + EQ_TB - 1) / EQ_TB);
     if (l.eqsym_t && !(l.flags & V2VAE_FLAG_EQ_MFMA_FWD)) {
-        const int per_cu = l.eqsym_t <= 25 ? 4 : 3;  // resident workgroups per CU (launch bounds)
+        const int per_cu = l.eqsym_t <= 25 ? 4 : l.eqsym_t <= 65 ? 3 : 2;  // resident workgroups per CU (launch bounds)
         const int nsy = l.eqsym_t <= 31 ? 2 : 1;                            // symbols per thread
         nblk = (nblk + nsy - 1) / nsy;
         const int nb = nblk < per_cu * CX_BLOCKS ? nblk : per_cu * CX_BLOCKS;
@@ -561,7 +580,9 @@ int launch_eq_fwd_cxb(const Lay& l, const float* y, const float* ws, float* xhat
         else if (l.eqsym_t == 25) hipLaunchKernelGGL(k_eq_fwd_sym<25>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat);
         else if (l.eqsym_t == 31) hipLaunchKernelGGL(k_eq_fwd_sym<31>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat);
         else if (l.eqsym_t == 47) hipLaunchKernelGGL(k_eq_fwd_sym<47>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat);
-        else hipLaunchKernelGGL(k_eq_fwd_sym<65>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat);
+        else if (l.eqsym_t == 65) hipLaunchKernelGGL(k_eq_fwd_sym<65>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat);
+        else if (l.eqsym_t == 79) hipLaunchKernelGGL(k_eq_fwd_sym<79>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat);
+        else hipLaunchKernelGGL(k_eq_fwd_sym<95>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat);
         return V2VAE_OK;
     }
     // persistent workgroups: as many per CU as their LDS image (sample tile + kernel table) allows, at most four

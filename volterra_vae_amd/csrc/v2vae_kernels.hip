@@ -230,7 +230,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     l.o_chanraw = take(l.chan ? 2 * (int64_t)l.L : 0);
     // real path: the equaliser output is formed in double and kept as a (float, float remainder) pair; the per-symbol kernels
     // add the remainder back when the xhat they are handed is bitwise the one the forward kernel produced
-    l.xlo = (l.mode == 0 && l.ns == 1) ? 1 : 0;
+    l.xlo = l.ns == 1 ? 1 : 0;
     l.o_xhi = take(l.xlo ? l.sym_cnt : 0);
     l.o_xlo = take(l.xlo ? l.sym_cnt : 0);
     l.o_mom = take((int64_t)(l.cx_real ? 2 : l.ns) * 4 * l.sym_cnt);
@@ -261,7 +261,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     l.o_eqcxbA = take(l.eqcxb_fwd ? (int64_t)l.eqcx_steps * l.eqcxb_nbl * 128 + l.eqcxb_nbl * 64 : 0);
     // symmetric-form forward on the vector pipe: half the multiply-adds of the matrix product and no padding of the lag count
     l.eqsym_t = l.use_eqcx ? (l.l2 <= 9 ? 9 : l.l2 <= 17 ? 17 : l.l2 <= 25 ? 25 : 31)
-                           : (l.use_eqcxb && l.l2 <= 65) ? (l.l2 <= 47 ? 47 : 65) : 0;
+                           : l.use_eqcxb ? (l.l2 <= 47 ? 47 : l.l2 <= 65 ? 65 : l.l2 <= 79 ? 79 : 95) : 0;
     // real model on the matrix-core path (see eqb16 above): forward in symmetric form, sums in double, up to 31 lags
     l.eqsymr = (l.cx_real && l.eqb16 && l.l2 <= 31) ? 1 : 0;
     if (l.eqsymr) l.eqsym_t = l.l2 <= 9 ? 9 : l.l2 <= 17 ? 17 : l.l2 <= 25 ? 25 : 31;
@@ -507,9 +507,10 @@ __device__ __forceinline__ void load_sample_tile(const Lay& l, const float* __re
     }
 }
 
-// one tile of EQ_TB symbols per block id.  ACC = double (real path): the sums are exact to double rounding and the result
-// leaves as a float plus its float remainder (workspace planes o_xhi / o_xlo), because the soft demapper amplifies an error
-// of xhat by 2 |xhat - a| / noise variance (~1e2) on its way into the equaliser and noise-scaling gradients.
+// one tile of EQ_TB symbols per block id.  The sums are formed in double (ACC; exact to double rounding) because the soft
+// demapper amplifies an error of xhat by 2 |xhat - a| / noise variance (~1e2) on its way into the equaliser and noise-scaling
+// gradients; on the real path the result leaves as a float plus its float remainder (workspace planes o_xhi / o_xlo), with two
+// streams as the correctly rounded float.
 template <typename ACC>
 __device__ __forceinline__ void d_eq_fwd_t(const GridCtx gc, Lay l, const float* __restrict__ y, float* __restrict__ ws,
                                            float* __restrict__ xhat) {
@@ -574,8 +575,7 @@ __device__ __forceinline__ void d_eq_fwd_t(const GridCtx gc, Lay l, const float*
 
 __device__ __forceinline__ void d_eq_fwd(const GridCtx gc, Lay l, const float* __restrict__ y, float* __restrict__ ws,
                                          float* __restrict__ xhat) {
-    if (l.xlo) d_eq_fwd_t<double>(gc, l, y, ws, xhat);
-    else d_eq_fwd_t<float>(gc, l, y, ws, xhat);
+    d_eq_fwd_t<double>(gc, l, y, ws, xhat);
 }
 
 __global__ __launch_bounds__(NT) void k_eq_fwd(Lay l, const float* __restrict__ y, float* __restrict__ ws,
@@ -1851,6 +1851,16 @@ int64_t v2vae_ws_offset_gmoments(const v2vae_problem* p) {
     return make_layout(p, &l) == V2VAE_OK ? l.o_gmom : -1;
 }
 
+int64_t v2vae_ws_offset_xhat_float(const v2vae_problem* p) {
+    Lay l;
+    return (make_layout(p, &l) == V2VAE_OK && l.xlo) ? l.o_xhi : -1;
+}
+
+int64_t v2vae_ws_offset_xhat_remainder(const v2vae_problem* p) {
+    Lay l;
+    return (make_layout(p, &l) == V2VAE_OK && l.xlo) ? l.o_xlo : -1;
+}
+
 int v2vae_prep_tables(const v2vae_problem* p, const float* h1, const float* h2, const float* k1, const float* k2,
                       void* ws, void* stream) {
     Lay l;
@@ -2215,14 +2225,28 @@ constexpr int STATIC_MAX_DEVICES = 64;
 std::mutex g_static_mutex;
 void* g_static_ptr[STATIC_MAX_DEVICES] = {};  // device address of static_scratch per device ordinal, filled at first use
 
-// Address of the calling thread's current device's copy of the array (resolved once per device).
-int static_scratch_ptr(unsigned char** out) {
-    int dev = -1;
-    hipError_t e = hipGetDevice(&dev);
+// Address of the copy of the array on the device that owns `stream` (the current device for the default stream), resolved
+// once per device with that device current.
+int static_scratch_ptr(hipStream_t stream, unsigned char** out) {
+    int cur = -1, dev = -1;
+    hipError_t e = hipGetDevice(&cur);
+    if (e == hipSuccess) {
+        dev = cur;
+        if (stream) {
+            hipDevice_t sd;
+            e = hipStreamGetDevice(stream, &sd);
+            if (e == hipSuccess) dev = (int)sd;
+        }
+    }
     if (e != hipSuccess || dev < 0 || dev >= STATIC_MAX_DEVICES) {
-        snprintf(g_last_error, sizeof(g_last_error), "v2vae_train_step_static: hipGetDevice: %s (device %d)",
+        snprintf(g_last_error, sizeof(g_last_error), "v2vae_train_step_static: device of the stream: %s (device %d)",
                  hipGetErrorString(e), dev);
         return V2VAE_ELAUNCH;
+    }
+    if (dev != cur) {   // kernels are launched with the current device's code object: the stream must belong to it
+        snprintf(g_last_error, sizeof(g_last_error), "v2vae_train_step_static: the stream belongs to device %d, the current "
+                 "device is %d", dev, cur);
+        return V2VAE_EINVAL;
     }
     std::lock_guard<std::mutex> lock(g_static_mutex);
     if (!g_static_ptr[dev]) {
@@ -2274,7 +2298,7 @@ int v2vae_train_step_static(const v2vae_problem* p, const v2vae_train_args* a, v
         return V2VAE_ESIZE;
     }
     unsigned char* base = nullptr;
-    if ((rc = static_scratch_ptr(&base))) return rc;
+    if ((rc = static_scratch_ptr((hipStream_t)stream, &base))) return rc;
     // the array keeps the previous call's contents: start every call from the all-zero state a fresh workspace has
     const hipError_t e = hipMemsetAsync(base, 0, c.total, (hipStream_t)stream);
     if (e != hipSuccess) {
@@ -2338,13 +2362,17 @@ int v2vae_fit_persistent(const v2vae_problem* p, const v2vae_fit_args* a, void* 
         if (took == 1) return launch_status();
     }
     if (!l.generic_elbo_ok || l.maxi_elbo != 1 || l.maxi_eq > 2) return V2VAE_ESIZE;
+    // the stage-by-stage kernel runs the generic stages only: every switch of the matrix-core paths off
     l.use_cx = 0;
+    l.cx_real = 0;
     l.cx_split = 0;
     l.use_cxb = 0;
     l.use_eqcx = 0;
     l.eqb16 = 0;
     l.use_eqcxb = 0;
     l.eqcxb_fwd = 0;
+    l.eqsymr = 0;
+    l.eqsym_t = 0;
     l.nblk_E = l.nblk_elbo;
     const int lds = l.lds_elbo > l.lds_eq ? l.lds_elbo : l.lds_eq;
 #define V2VAE_LAUNCH_FIT(CB, ME)                                                                                       \

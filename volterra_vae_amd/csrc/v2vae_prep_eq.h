@@ -39,18 +39,18 @@ __device__ __forceinline__ void d_prep_eqcxb(const Lay& l, const float* __restri
         ws[l.o_eqcxbA + n + idx] = (x < l2 && jj >= 0 && jj < l1) ? (plane == 0 ? k1r[jj] : k1i[jj]) : 0.f;
     }
     if (l.eqsym_t) {   // table of the symmetric-form forward kernel (k_eq_fwd_sym): one stream of (Re, Im) entries, row after row,
-                       // row a = [first-order weight of lag a, K'_aa, K'_a,a+1, ..., K'_a,T-1]; eight zero entries pad the end
+                       // row a = [K'_aa, K'_a,a+1, ..., K'_a,T-1, first-order weight of lag a]; eight zero entries pad the end
         const int T = l.eqsym_t, ne = T * (T + 1) / 2 + T;
         for (int idx = bid * NT + threadIdx.x; idx < ne + 8; idx += nb * NT) {
             float vr = 0.f, vi = 0.f;
             if (idx < ne) {
                 int a = 0, rem = idx;
                 while (rem >= T - a + 1) { rem -= T - a + 1; ++a; }
-                if (rem == 0) {
+                if (rem == T - a) {
                     const int jj = p1 + p2 - a;  // first-order tap that multiplies lag a
                     if (a < l2 && jj >= 0 && jj < l1) { vr = k1r[jj]; vi = k1i[jj]; }
                 } else {
-                    const int b = a + rem - 1;
+                    const int b = a + rem;
                     if (b < l2) {
                         const float sc = a == b ? 1.f : 2.f;   // K_ab y_a y_b + K_ba y_b y_a
                         vr = sc * (k2r[a * l2 + b] + k2r[b * l2 + a]);

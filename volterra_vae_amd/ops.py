@@ -124,6 +124,22 @@ class Plan:
         n = self.p.ns * 4 * self.p.sym_cnt
         return self.ws[off:off + n].view(self.p.ns, 4, self.p.sym_cnt)
 
+    def xhat_remainder(self):
+        """Real model: the float remainder [sym_cnt] of the last eq_fwd on this plan (a copy), else None.  Together with the
+        xhat that eq_fwd returned it is the equaliser output to double precision."""
+        off = lib.v2vae_ws_offset_xhat_remainder(C.byref(self.p))
+        return None if off < 0 else self.ws[off:off + self.p.sym_cnt].clone()
+
+    def set_xhat_remainder(self, xhat, xlo):
+        """Hands this plan an equaliser output that another plan computed: xhat [1, sym_cnt] (float) and its remainder xlo
+        [sym_cnt] go into the planes v2vae_demap_moments and v2vae_sym_bwd read."""
+        hi, lo = lib.v2vae_ws_offset_xhat_float(C.byref(self.p)), lib.v2vae_ws_offset_xhat_remainder(C.byref(self.p))
+        if hi < 0:
+            return
+        n = self.p.sym_cnt
+        self.ws[hi:hi + n].copy_(xhat.reshape(-1))
+        self.ws[lo:lo + n].copy_(xlo.reshape(-1))
+
     def gmoments_view(self):
         off = lib.v2vae_ws_offset_gmoments(C.byref(self.p))
         n = self.p.ns * 4 * self.p.sym_cnt
@@ -261,6 +277,10 @@ class PersistentFit:
 # registered torch custom ops (torch.ops.v2vae.*) over the C ABI, with autograd formulas
 # ------------------------------------------------------------------------------------------------
 # A Plan (geometry + workspace) is not a tensor, so the ops take its integer handle; `plan_from_handle` resolves it.
+# The ops are eager-only and stateful: forward and backward communicate through the plan's workspace (moments, dE/d(moments),
+# partial records, the scalar block), which no argument declares, so they must not be traced into a compiled graph that
+# reorders or deduplicates them; the generation counter of the plan (see _elbo_setup) covers every interleaving eager autograd
+# allows.
 _PLAN_COUNTER = itertools.count(1)
 _PLANS = weakref.WeakValueDictionary()
 
@@ -317,6 +337,7 @@ def _equaliser_setup(ctx, inputs, output):
     y, k1, k2, plan = inputs
     ctx.save_for_backward(y)
     ctx.plan = plan
+    ctx.plan_object = plan_from_handle(plan)   # the graph keeps the plan (its workspace) alive until the backward has run
     ctx.k_shapes = (k1.shape, None if k2 is None else k2.shape)
 
 
@@ -330,10 +351,12 @@ def _equaliser_backward(ctx, gx):
 _op_equaliser.register_autograd(_equaliser_backward, setup_context=_equaliser_setup)
 
 
-def _elbo_stages(pl: Plan, xh, y, snap, levels, prior):
+def _elbo_stages(pl: Plan, xh, y, snap, levels, prior, xlo=None):
     n = pl.sizes
     h1c, h2c, scc, nv = snap[:n[0]], snap[n[0]:n[0] + n[1]], snap[n[0] + n[1]:n[0] + n[1] + n[4]], snap[-1:]
     pl.prep_tables(h1=h1c, h2=h2c)
+    if xlo is not None and xlo.numel() == xh.numel():
+        pl.set_xhat_remainder(xh, xlo)
     pl.demap_moments(xh, levels, prior, scc, nv)
     pl.elbo_fused(y)
     pl.reduce_scalars()
@@ -344,36 +367,37 @@ def _elbo_stages(pl: Plan, xh, y, snap, levels, prior):
 @torch.library.custom_op("v2vae::elbo_loss", mutates_args=(), device_types="cuda")
 def _op_elbo_loss(xhat: torch.Tensor, y: torch.Tensor, h1: torch.Tensor, h2: torch.Tensor, scaling: torch.Tensor,
                   noise_var: torch.Tensor, levels: torch.Tensor, prior: torch.Tensor,
-                  plan: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+                  plan: int, xlo: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """(loss = KL + W log E, E, snapshot) through the fused ELBO kernels.  `snapshot` = [h1 | h2 | scaling | noise variance] as
     they were at this call: the backward op works from it, so later in-place updates of the parameters or of the noise
-    variance (lib/real_equalization.py:921-923) do not reach an earlier loss's gradients."""
+    variance (lib/real_equalization.py:921-923) do not reach an earlier loss's gradients.  `xlo` (real model, optional): the
+    float remainder of xhat from the equaliser's plan (Plan.xhat_remainder)."""
     pl = plan_from_handle(plan)
     _require_gpu_f32(y, "y")
     snap = torch.cat([h1.detach().reshape(-1), h2.detach().reshape(-1), scaling.detach().reshape(-1),
                       noise_var.detach().reshape(-1)[:1]])
-    _elbo_stages(pl, xhat.detach().contiguous(), y, snap, levels, prior)
+    _elbo_stages(pl, xhat.detach().contiguous(), y, snap, levels, prior, xlo)
     sc = pl.scal.clone()
     return sc[_lib.SCAL_LOSS].to(torch.float32), sc[_lib.SCAL_E].to(torch.float32), snap
 
 
 @_op_elbo_loss.register_fake
-def _(xhat, y, h1, h2, scaling, noise_var, levels, prior, plan):
+def _(xhat, y, h1, h2, scaling, noise_var, levels, prior, plan, xlo=None):
     return (xhat.new_empty((), dtype=torch.float32), xhat.new_empty((), dtype=torch.float32),
             xhat.new_empty(h1.numel() + h2.numel() + scaling.numel() + 1, dtype=torch.float32))
 
 
 @torch.library.custom_op("v2vae::elbo_loss_backward", mutates_args=(), device_types="cuda")
 def _op_elbo_loss_backward(gloss: torch.Tensor, xhat: torch.Tensor, y: torch.Tensor, snap: torch.Tensor, levels: torch.Tensor,
-                           prior: torch.Tensor, plan: int,
-                           restage: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+                           prior: torch.Tensor, plan: int, restage: bool,
+                           xlo: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """(d loss / d xhat, g_h1, g_h2, g_scaling) flat.  The backward reads dE/d(moments), the partial records and W / E from the
     plan's workspace; `restage` re-runs the forward stages first (needed if anything else ran on the plan since the forward)."""
     pl = plan_from_handle(plan)
     n = pl.sizes
     xh = xhat.detach().contiguous()
     if restage:
-        scc, nv = _elbo_stages(pl, xh, y, snap, levels, prior)
+        scc, nv = _elbo_stages(pl, xh, y, snap, levels, prior, xlo)
     else:
         scc, nv = snap[n[0] + n[1]:n[0] + n[1] + n[4]], snap[-1:]
     gs = gloss.detach().to(torch.float32).reshape(1).contiguous()
@@ -387,29 +411,30 @@ def _op_elbo_loss_backward(gloss: torch.Tensor, xhat: torch.Tensor, y: torch.Ten
 
 
 @_op_elbo_loss_backward.register_fake
-def _(gloss, xhat, y, snap, levels, prior, plan, restage):
+def _(gloss, xhat, y, snap, levels, prior, plan, restage, xlo=None):
     n = plan_from_handle(plan).sizes
     f = lambda k: xhat.new_empty(k, dtype=torch.float32)
     return torch.empty_like(xhat), f(n[0]), f(n[1]), f(n[4])
 
 
 def _elbo_setup(ctx, inputs, output):
-    xhat, y, h1, h2, scaling, noise_var, levels, prior, plan = inputs
-    ctx.save_for_backward(xhat.detach(), y, output[2], levels, prior)
+    xhat, y, h1, h2, scaling, noise_var, levels, prior, plan, xlo = inputs
+    ctx.save_for_backward(xhat.detach(), y, output[2], levels, prior, xlo)
     ctx.plan = plan
+    ctx.plan_object = plan_from_handle(plan)   # the graph keeps the plan (its workspace) alive until the backward has run
     ctx.shapes = (h1.shape, h2.shape, scaling.shape, xhat.shape)
     ctx.generation = [plan_from_handle(plan).elbo_generation]   # mutable: a re-staging backward brings it up to date
 
 
 def _elbo_backward(ctx, gloss, _gE, _gsnap):
-    xh, y, snap, levels, prior = ctx.saved_tensors
+    xh, y, snap, levels, prior, xlo = ctx.saved_tensors
     pl = plan_from_handle(ctx.plan)
     restage = pl.elbo_generation != ctx.generation[0]
-    gx, g_h1, g_h2, g_sc = torch.ops.v2vae.elbo_loss_backward(gloss, xh, y, snap, levels, prior, ctx.plan, restage)
+    gx, g_h1, g_h2, g_sc = torch.ops.v2vae.elbo_loss_backward(gloss, xh, y, snap, levels, prior, ctx.plan, restage, xlo)
     if restage:
         ctx.generation[0] = pl.elbo_generation
     s1, s2, s3, sx = ctx.shapes
-    return gx.view(sx), None, g_h1.view(s1), g_h2.view(s2), g_sc.view(s3), None, None, None, None
+    return gx.view(sx), None, g_h1.view(s1), g_h2.view(s2), g_sc.view(s3), None, None, None, None, None
 
 
 _op_elbo_loss.register_autograd(_elbo_backward, setup_context=_elbo_setup)
@@ -420,9 +445,9 @@ def equaliser(plan: Plan, y, k1, k2):
     return torch.ops.v2vae.equaliser(y, k1, k2, plan.handle)
 
 
-def elbo_loss(plan: Plan, xhat, y, h1, h2, scaling, noise_var, levels, prior):
+def elbo_loss(plan: Plan, xhat, y, h1, h2, scaling, noise_var, levels, prior, xlo=None):
     """(loss, E) as the registered op torch.ops.v2vae.elbo_loss (differentiable in xhat, h1, h2, scaling)."""
-    loss, E, _ = torch.ops.v2vae.elbo_loss(xhat, y, h1, h2, scaling, noise_var, levels, prior, plan.handle)
+    loss, E, _ = torch.ops.v2vae.elbo_loss(xhat, y, h1, h2, scaling, noise_var, levels, prior, plan.handle, xlo)
     return loss, E.detach()
 
 

@@ -22,7 +22,8 @@ import torch
 from . import ops
 from ._lib import V2VAEError
 from .ops import ElboLossFn, PersistentFit, Plan
-from .torch_components import SecondOrderVolterraSeries, StridedFIREqualiser, _check_dtype, _resolve_device
+from .torch_components import (SecondOrderVolterraSeries, StridedFIREqualiser, _check_dtype, _resolve_device,
+                               carry_remainder)
 
 
 class PackedAdamAMSGrad(torch.optim.Optimizer):
@@ -270,6 +271,9 @@ class VAESecondVolterraForward(GenericTorchBlindProbabilisticEqualizer):
         B = xh.shape[1]
         plan = self._plan(B * self.samples_per_symbol)
         q = torch.empty((1, self.constellation_size, B), dtype=self.dtype, device=self.torch_device)
+        xlo = getattr(xhat, "_v2vae_xlo", None)
+        if xlo is not None and xlo.numel() == B:   # the equaliser's own plan computed xhat: its remainder comes along
+            plan.set_xhat_remainder(xh, xlo)
         plan.demap_moments(xh, self._levels2d(), self.constellation_prior.view(1, -1), self.noise_scaling.detach().view(1, -1),
                            self._noise_var, q_out=q)
         return q[0]
@@ -280,7 +284,8 @@ class VAESecondVolterraForward(GenericTorchBlindProbabilisticEqualizer):
         plan = self._plan(n)
         loss, E = ElboLossFn.apply(plan, xhat.reshape(1, -1), y.reshape(1, -1).to(self.dtype).contiguous(), self.channel_h1,
                                    self._h2_argument(), self.noise_scaling.view(1, -1), self._noise_var,
-                                   self._levels2d(), self.constellation_prior.view(1, -1).contiguous())
+                                   self._levels2d(), self.constellation_prior.view(1, -1).contiguous(),
+                                   getattr(xhat, "_v2vae_xlo", None))
         if self.adaptive_noise_variance:
             with torch.no_grad():
                 self._noise_var[0] = E / (n - self.channel_memory + 1)
@@ -431,7 +436,8 @@ class LinearV2VAE(VAESecondVolterraForward):
                                    torch_device=self.torch_device, _storage=self._eq_storage[0])
 
     def forward(self, y):
-        return self.equaliser.forward(y[None, None, :]).squeeze()
+        out = self.equaliser.forward(y[None, None, :])
+        return carry_remainder(out, out.squeeze())
 
     def __repr__(self) -> str:
         return "LinV2VAE"
@@ -546,7 +552,8 @@ class LinearVAE(VAELinearForward):
                                    torch_device=self.torch_device, _storage=self._eq_storage[0])
 
     def forward(self, y):
-        return self.equaliser.forward(y[None, None, :]).squeeze()
+        out = self.equaliser.forward(y[None, None, :])
+        return carry_remainder(out, out.squeeze())
 
     def __repr__(self) -> str:
         return "LinVAE"

@@ -27,6 +27,16 @@ def _check_dtype(dtype):
         raise NotImplementedError(f"the HIP kernels compute in float32; dtype={dtype} is not supported")
 
 
+def carry_remainder(src: torch.Tensor, dst: torch.Tensor, n: int = None) -> torch.Tensor:
+    """`dst` is a reshaped / truncated view of the equaliser output `src`: the float remainder of the output (real model,
+    Plan.xhat_remainder) travels with it as the attribute `_v2vae_xlo`, which `_soft_demapping` / `_calculate_loss` of the
+    enclosing estimator hand to the soft demapper.  A tensor derived in any other way simply has no remainder."""
+    lo = getattr(src, "_v2vae_xlo", None)
+    if lo is not None:
+        dst._v2vae_xlo = lo if n is None else lo[:n]
+    return dst
+
+
 class _PlannedEqualiser(torch.nn.Module):
     """Shared machinery: a cache of kernel plans keyed by input length."""
 
@@ -52,8 +62,13 @@ class _PlannedEqualiser(torch.nn.Module):
         pad = (-n) % self.sps
         if pad:  # a trailing partial symbol sees zero padding, exactly as the reference's padded conv / unfold
             y = torch.nn.functional.pad(y, (0, pad))
-        out = EqualiserFn.apply(self._plan(y.shape[-1], y.shape[0]), y, k1, k2)
-        return out[0] if squeeze else out
+        plan = self._plan(y.shape[-1], y.shape[0])
+        out = EqualiserFn.apply(plan, y, k1, k2)
+        res = out[0] if squeeze else out
+        lo = plan.xhat_remainder() if squeeze else None
+        if lo is not None:
+            res._v2vae_xlo = lo
+        return res
 
 
 class SecondOrderVolterraSeries(_PlannedEqualiser):
@@ -120,7 +135,7 @@ class StridedFIREqualiser(_PlannedEqualiser):
     def forward(self, x: torch.Tensor):
         n_out = (x.shape[-1] + 2 * self._pad1 - self._l1) // self.sps + 1
         out = self._run(x.reshape(-1), self.weight.view(-1), None)
-        return out[:n_out].view(1, 1, -1)
+        return carry_remainder(out, out[:n_out].view(1, 1, -1), n_out)
 
     def print_parameters(self):
         print(self.weight)
@@ -148,7 +163,8 @@ class FIRfilter(_PlannedEqualiser):
 
     def forward(self, x):
         n_out = (x.shape[-1] + self.padding[0] + self.padding[1] - self.filter_length) // self.stride + 1
-        return self._run(x, torch.flip(self.weights, (0,)), None)[:n_out]
+        out = self._run(x, torch.flip(self.weights, (0,)), None)
+        return carry_remainder(out, out[:n_out], n_out)
 
     def print_parameters(self):
         print(self.weights)
