@@ -36,9 +36,9 @@ def algorithmic_flops_per_symbol(L, S, l1, l2, cplx):
     i.e. only work the kernels actually execute is counted (the stacked real-valued formulation would be 48 Le^2)."""
     c = 4 if cplx else 1
     return {
-        # complex, up to 65 lags (k_eq_fwd_sym): symmetric form, l2 (l2 + 1) / 2 + l2 complex multiply-adds (first-order kernel
+        # complex, up to 95 lags (k_eq_fwd_sym): symmetric form, l2 (l2 + 1) / 2 + l2 complex multiply-adds (first-order kernel
         # folded in); beyond that the full lag matrix is evaluated
-        "eq_fwd": 8 * (l2 * (l2 + 1) // 2 + l2) if (cplx and l2 <= 65) else c * (2 * l1 + 2 * l2 * l2 + 2 * l2),
+        "eq_fwd": 8 * (l2 * (l2 + 1) // 2 + l2) if (cplx and l2 <= 95) else c * (2 * l1 + 2 * l2 * l2 + 2 * l2),
         # the gradient planes are symmetric in the lag pair: the same count (k_eq_bwd_cx, up to 79 lags, accumulates the upper-
         # triangular 16x16 blocks only)
         "eq_bwd": 8 * (l2 * (l2 + 1) // 2 + l2) if (cplx and l2 <= 79) else c * (2 * l1 + 2 * l2 * l2),
@@ -311,6 +311,16 @@ def main():
                 traffic = next(v for k, v in tr.items() if "k_elbo_cx" in k)
         except Exception:
             traffic = None
+        # how busy the one fp32 pipe of a SIMD was in the dominant kernel: (matrix cycles + 4 x vector instructions) / elapsed
+        # cycles, from the committed SQ counter passes of the same command (tools/profile_step.sh, tools/pipe_bound.py)
+        pipe = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "latest_pipe.json")) as fh:
+                pj = json.load(fh)
+            if dom == "elbo_fused" and world == 1 and args.log2_symbols == 22 and (L, l1, order) == (25, 25, 16):
+                pipe = next(v["pipe_bound_frac"] for k, v in pj.items() if "k_elbo_cx" in k)
+        except Exception:
+            pipe = None
         out = {
             "metric": "V2VAE train-step symbols/sec (fwd+bwd) at 1/2/4/8 MI355X; % of HBM/MFMA roofline",
             "value": b_glob * args.steps / elapsed, "unit": "symbols/s", "n_gpus": world, "steps": args.steps,
@@ -320,7 +330,7 @@ def main():
                                    "Adam-AMSGrad, random-init (dirac) kernels, synthetic Wiener-Hammerstein ISI at 16 dB",
                        "symbols_per_gpu": b_per_gpu, "parallelism": f"halo-sharded dp{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic, "pipe_bound_frac": pipe,
                          "algorithmic_flops_per_symbol": fl[dom], "kernel_ms": kernel_ms[dom],
                          "whole_step_frac": step_flops / world / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_TFLOPS},
             "kernel_ms": kernel_ms, "final_loss": final_loss,

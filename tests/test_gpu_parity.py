@@ -127,11 +127,11 @@ def test_real_step_on_matrix_core_elbo_kernel_matches_reference_golden(name):
 @pytest.mark.parametrize("L,S,l1,l2,B,M", [(15, 2, 25, 25, 40000, 4), (25, 2, 9, 5, 33000, 4), (13, 1, 5, 3, 50000, 2),
                                            (15, 2, 5, 7, 6000, 4), (11, 2, 13, 17, 5000, 4), (9, 1, 3, 21, 4500, 2),
                                            (25, 2, 31, 31, 7000, 4), (13, 2, 25, 41, 5000, 4), (7, 3, 1, 1, 4200, 4),
-                                           (15, 2, 9, 79, 4100, 4)])
+                                           (15, 2, 9, 79, 4100, 4), (15, 2, 33, 65, 4200, 4), (9, 1, 47, 47, 4300, 2)])
 def test_real_large_batch_default_is_matrix_core_elbo_and_agrees_with_generic(L, S, l1, l2, B, M):
     """From 2^12 owned symbols on the real model runs on the matrix-core kernels by default; the generic kernels (reference-pinned
     by the goldens) on the same inputs are the check.  The shapes reach every table width of the symmetric-form forward
-    equaliser (up to 9 / 17 / 25 / 31 lags), second-order kernels beyond it (generic forward, matrix-core backward) and a
+    equaliser (up to 9 / 17 / 25 / 31 / 47 / 65 lags), second-order kernels beyond it (generic forward, matrix-core backward) and a
     first-order kernel longer than the second-order one (generic equaliser, matrix-core ELBO)."""
     from volterra_vae_amd import _lib
     from volterra_vae_amd.ops import Plan
@@ -407,9 +407,14 @@ def test_hard_decisions_equal_argmax_of_posteriors(ns, M, B):
     assert agree > 1 - 1e-4, agree
 
 
-@pytest.mark.parametrize("L,S,l1,l2,B,M", [(9, 2, 7, 5, 400, 16), (11, 4, 9, 5, 300, 8), (17, 8, 5, 3, 150, 2),
-                                           (15, 2, 63, 61, 700, 4), (7, 1, 3, 129, 600, 4), (6, 3, 255, 0, 500, 4)])
-def test_real_step_at_the_limits_of_the_parameter_ranges_matches_oracle(L, S, l1, l2, B, M):
+@pytest.mark.parametrize("L,S,l1,l2,B,M,mfma", [(9, 2, 7, 5, 400, 16, False), (11, 4, 9, 5, 300, 8, False), (17, 8, 5, 3, 150, 2, False),
+                                                (15, 2, 63, 61, 700, 4, False), (7, 1, 3, 129, 600, 4, False),
+                                                (6, 3, 255, 0, 500, 4, False),
+                                                # the matrix-core route of the real model with the symmetric-form forward (sums
+                                                # in double) at its longest kernels: 47- and 65-lag instances
+                                                (15, 2, 41, 41, 700, 4, True), (15, 2, 25, 47, 600, 4, True),
+                                                (13, 1, 65, 65, 500, 4, True), (15, 2, 9, 63, 650, 2, True)])
+def test_real_step_at_the_limits_of_the_parameter_ranges_matches_oracle(L, S, l1, l2, B, M, mfma):
     """Real model where the reference's goldens do not reach: PAM-16 / PAM-8 (the 16- and 8-level instantiations), 4 and 8
     samples per symbol, equalisers of 63 / 61 lags, the longest second-order (129 lags) and first-order (255 taps) kernels, an
     even channel memory.  Checked against the fp64 oracle (itself pinned to the reference's fp64 goldens to 1e-11) evaluated on
@@ -440,7 +445,9 @@ def test_real_step_at_the_limits_of_the_parameter_ranges_matches_oracle(L, S, l1
     loss, E, _ = orc.elbo_reference_form(xr, ty, th1, th2, tlv, prior, nv, tsc, S)
     loss.backward()
     lin = k2 is None
-    plan = Plan(ns=1, sps=S, l1=l1, pad1=(l1 - 1) // 2 if lin else l1 // 2, l2=l2, L=L, C_levels=M, n_glob=B * S, device="cuda")
+    from volterra_vae_amd import _lib
+    plan = Plan(ns=1, sps=S, l1=l1, pad1=(l1 - 1) // 2 if lin else l1 // 2, l2=l2, L=L, C_levels=M, n_glob=B * S, device="cuda",
+                flags=_lib.FLAG_REAL_MFMA if mfma else 0)
     out = run_step(plan, dev(y[None, :]), dev(h1), dev(h2), dev(k1), None if lin else dev(k2), dev(lv[None, :]),
                    dev(np.ones((1, M)) / M), dev(sc[None, :]), dev(np.array([nvf])))
     assert rel(out["xhat"][0], xr.detach().numpy()) < TOL_EXACT

@@ -231,3 +231,34 @@ def test_sweep_class_equals_individual_models():
         assert abs(one.optimizer.param_groups[0]["lr"] - sweep._current_lr) < 1e-12
         assert np.array_equal(ye, y2[m]) and np.array_equal(lc, c2[m])
         assert torch.equal(one._pack, sweep.params[m])
+
+
+def test_large_sweep_more_workgroups_than_compute_units_equals_individual_fits():
+    """640 models in one launch - more workgroups than the 256 compute units hold at once, so workgroups of later models start
+    as earlier ones retire - on 16 distinct sequences shared round-robin (the layout of the benchmark's sweep workload); a
+    sample of the models, among them the first, the last and those around the 256 / 512 boundaries, must equal individual
+    drop-in fits bit for bit (lib/real_equalization.py:482-502 once per model, main_v2vae.py:75-91)."""
+    from volterra_vae_amd.real_equalization import SecondVolterraV2VAE
+    from volterra_vae_amd.sweep import SecondVolterraV2VAESweep
+    from volterra_vae_amd.synth import nonlinear_isi, pam_constellation
+    S, B, L, l1, l2, nb, M = 2, 500, 15, 25, 25, 10, 640
+    const = pam_constellation(4)
+    snrs = np.linspace(10.0, 25.0, 16)
+    base = np.stack([nonlinear_isi(nb * B, const, S, snr, np.random.default_rng(300 + i))[0] for i, snr in enumerate(snrs)])
+    idx = np.arange(M) % 16
+    nv0 = 10 ** (-snrs[idx] / 10)
+    dev = torch.device("cuda")
+    sweep = SecondVolterraV2VAESweep(M, L, l1, l2, 5e-3, const, S, B, noise_variance=nv0, torch_device=dev)
+    assert sweep._fit.on_chip
+    y_eq, curves = sweep.fit(base[idx])
+    assert np.isfinite(curves).all() and y_eq.shape == (M, nb * B)
+    # models that share a sequence and a starting noise variance are the same computation
+    assert np.array_equal(curves[3], curves[3 + 16 * 39]) and np.array_equal(y_eq[3], y_eq[3 + 16 * 39])
+    for m in (0, 1, 17, 255, 256, 257, 300, 511, 512, 513, 638, 639):
+        one = SecondVolterraV2VAE(channel_memory=L, learning_rate=5e-3, constellation=const, samples_per_symbol=S, batch_size=B,
+                                  noise_variance=float(nv0[m]), torch_device=dev, equaliser_n_lags1=l1, equaliser_n_lags2=l2)
+        one.initialize_optimizer()
+        ye, lc = one.fit(base[idx[m]])
+        assert np.array_equal(ye, y_eq[m]) and np.array_equal(lc, curves[m]), m
+        assert torch.equal(one._pack, sweep.params[m]), m
+        assert torch.equal(one._noise_var[0], sweep.noise_variance[m]), m

@@ -15,6 +15,7 @@ timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VALU_MF
 python3 tools/hbm_traffic.py $OUT/fetch $OUT/write $OUT/hbm_traffic.json > $OUT/hbm_traffic.txt
 python3 tools/pmc_summary.py $OUT/sq1 > $OUT/pmc_sq1.txt
 python3 tools/pmc_summary.py $OUT/sq2 > $OUT/pmc_sq2.txt
+python3 tools/pipe_bound.py $OUT/sq1 $OUT/sq2 $OUT/pipe.json > $OUT/pipe.txt
 find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 # keep only the small summaries
 rm -rf $OUT/stats $OUT/fetch $OUT/write $OUT/sq1 $OUT/sq2

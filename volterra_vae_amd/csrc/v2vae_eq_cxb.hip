@@ -441,7 +441,7 @@ template <int T>
 __global__ __launch_bounds__(NT, 2) void k_eq_fwd_symr(Lay l, const float* __restrict__ y, float* __restrict__ ws, float* __restrict__ xhat) {
     extern __shared__ float sm[];
     float* tile = sm;
-    constexpr int NSY = 2, TB = NSY * EQ_TB;
+    constexpr int NSY = T <= 31 ? 2 : 1, TB = NSY * EQ_TB;   // (the samples are held as doubles: two symbols per thread up to 31 lags)
     const int tid = threadIdx.x;
     const float* tab0 = ws + l.o_eqsym;
     const int64_t sym_hi = l.sym_lo + l.sym_cnt;
@@ -547,14 +547,17 @@ int launch_prep_eqsymr(const Lay& l, const float* k1, const float* k2, float* ws
 }
 
 int launch_eq_fwd_symr(const Lay& l, const float* y, float* ws, float* xhat, hipStream_t st) {
-    const int nt = (int)((l.sym_cnt + 2 * EQ_TB - 1) / (2 * EQ_TB));
+    const int nsy = l.eqsym_t <= 31 ? 2 : 1;   // symbols per thread
+    const int nt = (int)((l.sym_cnt + nsy * EQ_TB - 1) / (nsy * EQ_TB));
     const int nb = nt < 2 * CX_BLOCKS ? nt : 2 * CX_BLOCKS;   // resident workgroups: two per CU (launch bounds)
-    const int lds = (l.tile_len + (l.eqsym_t - l.l2) + EQ_TB * l.S) * 4;
+    const int lds = (l.tile_len + (l.eqsym_t - l.l2) + (nsy - 1) * EQ_TB * l.S) * 4;
     switch (l.eqsym_t) {
         case 9: hipLaunchKernelGGL(k_eq_fwd_symr<9>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat); break;
         case 17: hipLaunchKernelGGL(k_eq_fwd_symr<17>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat); break;
         case 25: hipLaunchKernelGGL(k_eq_fwd_symr<25>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat); break;
         case 31: hipLaunchKernelGGL(k_eq_fwd_symr<31>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat); break;
+        case 47: hipLaunchKernelGGL(k_eq_fwd_symr<47>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat); break;
+        case 65: hipLaunchKernelGGL(k_eq_fwd_symr<65>, dim3(nb), dim3(NT), lds, st, l, y, ws, xhat); break;
         default: return V2VAE_ESIZE;
     }
     return V2VAE_OK;

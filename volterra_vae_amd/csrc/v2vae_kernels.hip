@@ -262,9 +262,9 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     // symmetric-form forward on the vector pipe: half the multiply-adds of the matrix product and no padding of the lag count
     l.eqsym_t = l.use_eqcx ? (l.l2 <= 9 ? 9 : l.l2 <= 17 ? 17 : l.l2 <= 25 ? 25 : 31)
                            : l.use_eqcxb ? (l.l2 <= 47 ? 47 : l.l2 <= 65 ? 65 : l.l2 <= 79 ? 79 : 95) : 0;
-    // real model on the matrix-core path (see eqb16 above): forward in symmetric form, sums in double, up to 31 lags
-    l.eqsymr = (l.cx_real && l.eqb16 && l.l2 <= 31) ? 1 : 0;
-    if (l.eqsymr) l.eqsym_t = l.l2 <= 9 ? 9 : l.l2 <= 17 ? 17 : l.l2 <= 25 ? 25 : 31;
+    // real model on the matrix-core path (see eqb16 above): forward in symmetric form, sums in double, up to 65 lags
+    l.eqsymr = (l.cx_real && l.eqb16 && l.l2 <= 65) ? 1 : 0;
+    if (l.eqsymr) l.eqsym_t = l.l2 <= 9 ? 9 : l.l2 <= 17 ? 17 : l.l2 <= 25 ? 25 : l.l2 <= 31 ? 31 : l.l2 <= 47 ? 47 : 65;
     l.o_eqsym = take(l.eqsym_t ? l.eqsym_t * (l.eqsym_t + 1) + 2 * l.eqsym_t + 16 : 0);
     l.o_part_eqcxb = take((l.use_eqcxb && !l.eqb16) ? (int64_t)l.nblk_eq * l.eqcxb_rec : 0);
     l.o_tot_eqcxb = take((l.use_eqcxb && !l.eqb16) ? l.eqcxb_rec : 0);
