@@ -41,7 +41,7 @@ def test_single_step_against_reference(case, generic, monkeypatch):
     xhat = m.forward(y)
     assert rel(xhat, g64["xhat"]) < TOL
     q = m._soft_demapping(xhat)
-    assert rel(q, g64["q"]) < 1e-4
+    assert rel(q, g64["q"]) < TOL
     loss = m._calculate_loss(xhat, y)
     assert abs(float(loss.detach()) - float(g64["loss"])) < TOL * abs(float(g64["loss"]))
     assert abs(float(m.noise_variance) - float(g64["noise_variance_out"])) < TOL * float(g64["noise_variance_out"])

@@ -12,7 +12,8 @@
 // The NB^2 x 40 constant A-operand images (92 KB per phase at NB = 3) do not fit LDS next to the tiles; they stay in
 // global memory (L2-resident, every wave streams the same sequence) and are fetched ahead of the MFMA chains.
 // One workgroup = 4 waves, ONE per SIMD: the per-block register images of z, w, ... and the NB^2 gradient tiles need the
-// full 512-register budget.  The per-(window, tap) algebra runs on tap PAIRS (accumulator registers 2 p, 2 p + 1 hold
+// full 512-register budget - except with one block and a tap on the side (17 taps), which fits 256 registers: that instance
+// runs eight waves, two per SIMD, on 256-window tiles (1.15 against 1.38 ms per 2^22 symbols).  The per-(window, tap) algebra runs on tap PAIRS (accumulator registers 2 p, 2 p + 1 hold
 // neighbouring taps) in explicit two-wide arithmetic over structure-of-arrays moment planes.
 //
 // Tap counts of the form 16 NB + 1 (L = 65 at two samples per symbol: 33) would waste a whole block row and column on one
@@ -27,9 +28,6 @@
 
 namespace v2vae {
 
-constexpr int CXB_NW = 4;
-constexpr int CXB_NT = CXB_NW * 64;
-constexpr int CXB_NU = CXB_TWB / 32;
 
 // compact tap k of phase r -> channel tap index or -1
 __device__ __forceinline__ int cxb_tap(const Lay& l, int r, int k) {
@@ -102,9 +100,9 @@ __global__ __launch_bounds__(NT) void k_prep_cxb(Lay l, const float* __restrict_
 }
 
 template <int S, int NB, int XT>
-__global__ __launch_bounds__(CXB_NT) void k_elbo_cxb(Lay l, const float* __restrict__ y, float* __restrict__ ws) {
+__global__ __launch_bounds__(cxb_nw(NB, XT) * 64) void k_elbo_cxb(Lay l, const float* __restrict__ y, float* __restrict__ ws) {
     extern __shared__ __align__(16) float sm[];
-    constexpr int TWB = CXB_TWB, NU = CXB_NU, TP = XT ? CXB_TPX : CX_TP, NW = CXB_NW;
+    constexpr int TWB = cxb_twb(NB, XT), NU = TWB / 32, TP = XT ? CXB_TPX : CX_TP, NW = cxb_nw(NB, XT), CXB_NT = NW * 64;
     constexpr int LEB = 16 * (NB + XT), EX = 16 * NB, MS = TWB + LEB + 16, NSIG = 32 + LEB, NWP = NW / S;
     constexpr int REC = 2 * LEB * LEB + 4 * LEB;
     constexpr int STG = 7 * MS + 2 * S * TWB;
@@ -761,7 +759,7 @@ int launch_elbo_cxb(const Lay& l, const float* y, float* ws, hipStream_t st) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_elbo_cxb<SS, NBB, XTT>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 lds) != hipSuccess)                                                                        \
             return V2VAE_ELAUNCH;                                                                                          \
-        hipLaunchKernelGGL((k_elbo_cxb<SS, NBB, XTT>), dim3(l.nblk_cxb), dim3(CXB_NT), lds, st, l, y, ws);                  \
+        hipLaunchKernelGGL((k_elbo_cxb<SS, NBB, XTT>), dim3(l.nblk_cxb), dim3(cxb_nw(NBB, XTT) * 64), lds, st, l, y, ws);                  \
     } while (0)
     if (l.cxb_xt) {
         if (l.cxb_nbk == 1) { if (l.S == 1) V2VAE_LAUNCH_CXB(1, 1, 1); else V2VAE_LAUNCH_CXB(2, 1, 1); }

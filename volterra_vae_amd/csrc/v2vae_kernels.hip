@@ -167,12 +167,15 @@ int make_layout(const v2vae_problem* p, Lay* out) {
         l.cxb_leb = 16 * l.cxb_nb;
         l.cxb_rec = 2 * l.cxb_leb * l.cxb_leb + 4 * l.cxb_leb;
         {
+            const int CXB_TWB = cxb_twb(l.cxb_nbk, l.cxb_xt), CXB_NW = cxb_nw(l.cxb_nbk, l.cxb_xt);
+            l.cxb_twbv = CXB_TWB;
+            l.cxb_nwv = CXB_NW;
             const int tsb = CXB_TWB - l.kmax;
             l.ntile_cxb = l.use_cxb ? (int)((l.own_cnt + tsb - 1) / tsb) : 0;
             l.nblk_cxb = l.ntile_cxb < CX_BLOCKS ? l.ntile_cxb : CX_BLOCKS;
             const int ms = CXB_TWB + l.cxb_leb + 16, nsig = 32 + l.cxb_leb;
-            l.lds_cxb = ((7 * ms + 2 * l.S * CXB_TWB) + l.S * 4 * l.cxb_leb + 4 * 32 * (l.cxb_xt ? CXB_TPX : CX_TP) +
-                         l.S * (CXB_TWB / 32) * 4 * nsig + (l.S * l.cxb_rec > 4 * 32 * 81 ? l.S * l.cxb_rec : 4 * 32 * 81) +
+            l.lds_cxb = ((7 * ms + 2 * l.S * CXB_TWB) + l.S * 4 * l.cxb_leb + CXB_NW * 32 * (l.cxb_xt ? CXB_TPX : CX_TP) +
+                         l.S * (CXB_TWB / 32) * 4 * nsig + (l.S * l.cxb_rec > CXB_NW * 32 * 81 ? l.S * l.cxb_rec : CXB_NW * 32 * 81) +
                          (l.cxb_xt ? l.S * 2 * l.cxb_leb : 0)) * 4;   // records / per-wave [32][81] transposing buffers share memory
         }
         l.nblk_E = l.use_cx ? l.nblk_cx + G2_NE : (l.use_cxb ? l.nblk_cxb + G2_NE : l.nblk_elbo);   // + 1: the lagged-product term of E (k_g2_cx)

@@ -29,7 +29,11 @@ constexpr int CX_REC = 576;          // floats per (workgroup, phase) record of 
 constexpr int CX_IMG = 2112;         // floats of the block-tile kernel's LDS image of its 32x32 accumulator tile (+ vectors)
 constexpr int SUM_CHUNKS = 32;       // first-stage groups of the two-stage partial-record sums
 constexpr int CX_BLOCKS = 256;       // one workgroup per CU (the LDS image takes most of a CU)
-constexpr int CXB_TWB = 512;         // windows per phase per block tile of the blocked kernel
+// Blocked ELBO kernel: waves per workgroup and windows per phase per block tile.  One block plus a tap on the side (17 active
+// taps) fits 256 registers per lane without spills: eight waves (two per SIMD) on 256-window tiles; the longer tap counts need
+// the 512-register budget of one wave per SIMD: four waves on 512-window tiles.
+__host__ __device__ constexpr int cxb_nw(int nbk, int xt) { return (nbk == 1 && xt) ? 8 : 4; }
+__host__ __device__ constexpr int cxb_twb(int nbk, int xt) { return (nbk == 1 && xt) ? 256 : 512; }
 constexpr int CXB_TPX = 35;          // row pitch of its transposing buffer when an extra tap rides along (columns 32, 33)
 constexpr int CX_MAXLAG = 48;        // lagged products kept for sum s s^T (largest blocked tap count)
 constexpr int G2C_D = 4 + 2 * (2 * CX_MAXLAG + 8);   // offset of the real coefficients D[lag] in the table at Lay::o_g2c
@@ -77,6 +81,7 @@ struct Lay {
     // soft demapper, its samples read as zero) and the kernel adds the terms of the diagonal quirk (dq = diag(h2), d = 2 diag(h2))
     int cx_real;
     int64_t cx_rl, o_gpk;
+    int cxb_nwv, cxb_twbv;   // waves per workgroup / windows per tile of the blocked ELBO kernel instance that serves the shape
     // blocked matrix-core ELBO path (complex, 16 < active taps per phase <= 48): taps in blocks of 16
     // cxb_nb blocks give the stride cxb_leb of tables and records; the kernel runs cxb_nbk blocks on the matrix cores plus cxb_xt
     // (0 or 1) extra tap on the side (tap counts 16 cxb_nbk + 1), else cxb_nbk = cxb_nb
