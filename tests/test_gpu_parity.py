@@ -232,7 +232,10 @@ def _complex_inputs(seed, L, S, l1, l2, B, M):
                                            (25, 2, 25, 25, 1500, 4), (15, 2, 11, 9, 4000, 8), (5, 1, 1, 1, 70, 2),
                                            (4, 2, 1, 3, 513, 2), (31, 2, 31, 31, 1025, 4),
                                            # the largest level count (256-QAM) and sample counts per symbol up to the limit of 8
-                                           (13, 2, 7, 5, 500, 16), (9, 4, 5, 3, 300, 4), (17, 8, 9, 5, 200, 2)])
+                                           (13, 2, 7, 5, 500, 16), (9, 4, 5, 3, 300, 4), (17, 8, 9, 5, 200, 2),
+                                           # four samples per symbol on the run ELBO kernel (two waves per phase, 96-window
+                                           # strips): 9 and 16 active taps per phase (13- and 16-step instances), several strips
+                                           (33, 4, 9, 5, 1300, 4), (61, 4, 7, 3, 900, 2), (25, 4, 25, 25, 700, 4)])
 def test_complex_step_matches_oracle(L, S, l1, l2, B, M):
     from oracle import v2vae_oracle as orc
     from volterra_vae_amd.ops import Plan
@@ -413,7 +416,9 @@ def test_hard_decisions_equal_argmax_of_posteriors(ns, M, B):
                                                 # the matrix-core route of the real model with the symmetric-form forward (sums
                                                 # in double) at its longest kernels: 47- and 65-lag instances
                                                 (15, 2, 41, 41, 700, 4, True), (15, 2, 25, 47, 600, 4, True),
-                                                (13, 1, 65, 65, 500, 4, True), (15, 2, 9, 63, 650, 2, True)])
+                                                (13, 1, 65, 65, 500, 4, True), (15, 2, 9, 63, 650, 2, True),
+                                                # four samples per symbol on the matrix-core route (run ELBO kernel, real instance)
+                                                (29, 4, 9, 5, 900, 4, True)])
 def test_real_step_at_the_limits_of_the_parameter_ranges_matches_oracle(L, S, l1, l2, B, M, mfma):
     """Real model where the reference's goldens do not reach: PAM-16 / PAM-8 (the 16- and 8-level instantiations), 4 and 8
     samples per symbol, equalisers of 63 / 61 lags, the longest second-order (129 lags) and first-order (255 taps) kernels, an

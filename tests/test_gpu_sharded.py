@@ -77,7 +77,8 @@ def _run_world(world, tmp_path, shape=(25, 2, 25, 25, 4, 3000), tag="", **extra)
 
 # (L, S, l1, l2, levels per axis, symbols): the headline shape; the long-channel / long-equaliser 64-QAM shape of the
 # 8-GPU configuration (blocked matrix-core kernels with non-zero own_lo / sym_lo / y_lo on rank 1); one sample per symbol
-SHARD_SHAPES = [(25, 2, 25, 25, 4, 3000), (65, 2, 65, 65, 8, 3000), (25, 1, 25, 25, 4, 3000), (65, 2, 25, 25, 8, 2500)]
+SHARD_SHAPES = [(25, 2, 25, 25, 4, 3000), (65, 2, 65, 65, 8, 3000), (25, 1, 25, 25, 4, 3000), (65, 2, 25, 25, 8, 2500),
+                (33, 4, 9, 5, 4, 2600)]   # four samples per symbol: the run ELBO kernel with two waves per phase
 
 
 @pytest.mark.parametrize("shape", SHARD_SHAPES, ids=lambda s: "L%dS%dl%d_%dM%dB%d" % s)

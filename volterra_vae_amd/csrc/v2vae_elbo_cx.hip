@@ -461,7 +461,7 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
 // ------------------------------------------------------------------------------------------------------------
 // The same mathematics without a workgroup barrier in the main loop: every wave works alone on a RUN of consecutive windows
 // of one phase (the run's symbols [a, b) plus the kmax windows before a, which it recomputes un-owned, exactly as a block tile
-// does above).  A run is cut into strips of CX3_WT windows whose moments the wave stages in its own LDS planes; the per-symbol
+// does above).  A run is cut into strips of cx3_wt(S) windows whose moments the wave stages in its own LDS planes; the per-symbol
 // gradients (symbol = window + tap) are accumulated with LDS float adds into the wave's own per-symbol arrays - one array per
 // lane half, so that no two lanes of one instruction ever meet at an address and the result is bit-reproducible - and carried
 // from strip to strip; a strip's finished symbols go straight to global memory.  With two phases (S = 2) the two waves that cover
@@ -470,17 +470,19 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
 // NK = k-steps of the H X and H w products: 16, or 13 when no phase has more than 13 active taps (the k index then runs over
 // [stream][13 taps] and three values of the H w operand change lane halves).
 // ------------------------------------------------------------------------------------------------------------
-constexpr int CX3_WT = 192;                 // windows per strip
-constexpr int CX3_MS = CX3_WT + 32;         // staged symbols per strip (16 used beyond the windows; 32 keeps the gradient
-                                            // update of a slab, 64 lanes wide, inside the arrays)
+// windows per strip: 192 with one or two phases; 96 with four samples per symbol, whose four per-phase tables leave the eight
+// wave areas less of the 160 KB
+__host__ __device__ constexpr int cx3_wt(int S) { return S <= 2 ? 192 : 96; }
+// staged symbols per strip (16 used beyond the windows; 32 keeps the gradient update of a slab, 64 lanes wide, inside the arrays)
+__host__ __device__ constexpr int cx3_ms(int S) { return cx3_wt(S) + 32; }
 constexpr int CX3_NW = 8;                   // waves per workgroup
 constexpr int CX3_ADB = 16 * 32 + 4;        // 4-vectors of the anti-diagonal buffer (two planes of 8 tap-pair rows of 32 windows, a zero vector behind each)
 // floats of one wave's private LDS: 7 moment planes, the per-symbol gradient 4-vectors, the anti-diagonal buffer (which the
 // transposing buffer of the rho / sigma rows shares: the two are used one after the other within a slab)
-constexpr int CX3_WAVE_F = 7 * CX3_MS + 4 * CX3_MS + 4 * CX3_ADB;
+__host__ __device__ constexpr int cx3_wave_f(int S) { return 7 * cx3_ms(S) + 4 * cx3_ms(S) + 4 * CX3_ADB; }
 
 __host__ __device__ constexpr int cx3_lds_floats(int S, int NK) {
-    return S * 2 * NK * 64 + S * 64 + CX3_NW * CX3_WAVE_F;
+    return S * 2 * NK * 64 + S * 64 + CX3_NW * cx3_wave_f(S);
 }
 
 // REAL: the real model (one stream).  Everything that is identically zero with a zero quadrature stream is a compile-time zero in
@@ -494,7 +496,7 @@ __host__ __device__ constexpr int cx3_lds_floats(int S, int NK) {
 template <int S, int NK, bool REAL>
 __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __restrict__ y, float* __restrict__ ws) {
     extern __shared__ __align__(16) float sm[];
-    constexpr int WT = CX3_WT, MS = CX3_MS, TP = CX_TP, NW = CX3_NW;
+    constexpr int WT = cx3_wt(S), MS = cx3_ms(S), CX3_WAVE_F = cx3_wave_f(S), TP = CX_TP, NW = CX3_NW;
     constexpr int NWP = NW / S;
     constexpr int CX3_NT = NW * 64;
     static_assert(NK == 16 || NK == 13, "k-step counts with an operand schedule");
@@ -1166,7 +1168,7 @@ __global__ __launch_bounds__(NT, 5) void k_g2_cx(Lay l, float* __restrict__ ws) 
                 const float gka = fmaf(4.f, s_out[0][i & 3][i >> 2], k0r), gkb = fmaf(4.f, s_out[1][i & 3][i >> 2], k0i);
                 const float gt = 4.f * s_out[2][i & 3][i >> 2];
                 if (l.cx_split) {
-                    reinterpret_cast<f32x4*>(ws + l.o_gpk)[2 * st + (m - l.sym_lo)] = f32x4{gka, gkb, gt, s_cf[2]};
+                    reinterpret_cast<f32x4*>(ws + l.o_gpk)[(int64_t)S * st + (m - l.sym_lo)] = f32x4{gka, gkb, gt, s_cf[2]};
                 } else {
                     float* gp = gmom + (m - l.sym_lo);
                     gp[2 * st] = gka;
@@ -1229,7 +1231,7 @@ __global__ __launch_bounds__(NT, 5) void k_g2_cx(Lay l, float* __restrict__ ws) 
             float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
             for (int w = 0; w < NT / 64; ++w) { a += s_e[w][0]; b += s_e[w][1]; c += s_e[w][2]; d += s_e[w][3]; }
             if (l.cx_split) {
-                reinterpret_cast<f32x4*>(ws + l.o_gpk)[2 * st + (m - l.sym_lo)] = f32x4{a, b, d, c};
+                reinterpret_cast<f32x4*>(ws + l.o_gpk)[(int64_t)S * st + (m - l.sym_lo)] = f32x4{a, b, d, c};
             } else {
                 float* gp = gmom + (m - l.sym_lo);
                 gp[2 * st] = a; gp[6 * st] = b; gp[3 * st] = c; gp[7 * st] = c;
@@ -1262,9 +1264,11 @@ int launch_elbo_cx(const Lay& l, const float* y, float* ws, hipStream_t st) {
     const bool k13 = l.LE <= 13;
     const int lds = cx3_lds_floats(l.S, k13 ? 13 : 16) * 4;
     if (l.cx_real) {
+        if (l.S == 4) return k13 ? launch_cx(k_elbo_cx3<4, 13, true>, l, lds, y, ws, st) : launch_cx(k_elbo_cx3<4, 16, true>, l, lds, y, ws, st);
         if (l.S == 1) return k13 ? launch_cx(k_elbo_cx3<1, 13, true>, l, lds, y, ws, st) : launch_cx(k_elbo_cx3<1, 16, true>, l, lds, y, ws, st);
         return k13 ? launch_cx(k_elbo_cx3<2, 13, true>, l, lds, y, ws, st) : launch_cx(k_elbo_cx3<2, 16, true>, l, lds, y, ws, st);
     }
+    if (l.S == 4) return k13 ? launch_cx(k_elbo_cx3<4, 13, false>, l, lds, y, ws, st) : launch_cx(k_elbo_cx3<4, 16, false>, l, lds, y, ws, st);
     if (l.S == 1) return k13 ? launch_cx(k_elbo_cx3<1, 13, false>, l, lds, y, ws, st) : launch_cx(k_elbo_cx3<1, 16, false>, l, lds, y, ws, st);
     return k13 ? launch_cx(k_elbo_cx3<2, 13, false>, l, lds, y, ws, st) : launch_cx(k_elbo_cx3<2, 16, false>, l, lds, y, ws, st);
 }

@@ -137,10 +137,12 @@ int make_layout(const v2vae_problem* p, Lay* out) {
         const int cap_dm = 256 * (l.C <= 4 ? 4 : l.C <= 8 ? 2 : 1);
         l.nblk_dm = (int)(nb < cap_dm ? nb : cap_dm);
     }
-    // ---- matrix-core ELBO path: complex model, <= 16 active taps per stream and phase, S in {1, 2}
-    l.use_cx = (l.mode == 1 && l.LE <= 16 && l.S <= 2 && !(l.flags & V2VAE_FLAG_GENERIC)) ? 1 : 0;
+    // ---- matrix-core ELBO path: complex model, <= 16 active taps per stream and phase, S in {1, 2}; the run kernel also
+    //      serves four samples per symbol (two waves per phase)
+    const bool run_s = l.S <= 2 || (l.S == 4 && !(l.flags & V2VAE_FLAG_ELBO_TILES));
+    l.use_cx = (l.mode == 1 && l.LE <= 16 && run_s && !(l.flags & V2VAE_FLAG_GENERIC)) ? 1 : 0;
     // the real model runs the same kernel on a zero quadrature stream (large batches; any batch on request)
-    l.cx_real = (l.mode == 0 && l.ns == 1 && l.chan == 0 && l.LE <= 16 && l.S <= 2 &&
+    l.cx_real = (l.mode == 0 && l.ns == 1 && l.chan == 0 && l.LE <= 16 && run_s &&
                  !(l.flags & (V2VAE_FLAG_GENERIC | V2VAE_FLAG_ELBO_TILES)) &&
                  (l.own_cnt >= 4096 || (l.flags & V2VAE_FLAG_REAL_MFMA))) ? 1 : 0;
     if (l.cx_real) l.use_cx = 1;
@@ -238,7 +240,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     l.o_xlo = take(l.xlo ? l.sym_cnt : 0);
     l.o_mom = take((int64_t)(l.cx_real ? 2 : l.ns) * 4 * l.sym_cnt);
     l.o_gmom = take((int64_t)(l.cx_real ? 2 : l.ns) * 4 * l.sym_cnt);
-    l.o_gpk = take(l.cx_split ? 12 * l.sym_cnt : 0);
+    l.o_gpk = take(l.cx_split ? 4 * (int64_t)(l.S + 1) * l.sym_cnt : 0);
     l.o_part_elbo = take((int64_t)l.nblk_elbo * l.rec_elbo);
     l.o_part_eq = take((int64_t)l.nblk_eq * l.rec_eq);
     l.o_part_sym = take((int64_t)l.nblk_sym * l.rec_sym);
@@ -779,12 +781,13 @@ __device__ __forceinline__ void d_sym_bwd(const GridCtx gc, Lay l, const float* 
                 ng[c][3] = (cx_path && b >= l.kmax && b * l.S + l.S - 1 < l.W) ? g4c : g[3 * l.sym_cnt];
             }
         }
-        if (own && l.cx_split) {   // run kernel: three per-symbol 4-vectors (phase 0, phase 1, k_g2_cx)
+        if (own && l.cx_split) {   // run kernel: S + 1 per-symbol 4-vectors (one per phase, then k_g2_cx's)
             typedef float v4 __attribute__((ext_vector_type(4)));
             const v4* pk = reinterpret_cast<const v4*>(ws + l.o_gpk) + i;
             v4 p0 = pk[0];
-            const v4 p2 = pk[2 * l.sym_cnt];
-            if (l.S == 2) p0 += pk[l.sym_cnt];
+            const v4 p2 = pk[(int64_t)l.S * l.sym_cnt];
+            if (l.S >= 2) p0 += pk[l.sym_cnt];
+            if (l.S == 4) { p0 += pk[2 * l.sym_cnt]; p0 += pk[3 * l.sym_cnt]; }
             ng[0][0] = p0.x; ng[0][1] = p0.z + p2.z; ng[0][2] = p2.x; ng[0][3] = p2.w;
             ng[1][0] = p0.y; ng[1][1] = p0.w + p2.z; ng[1][2] = p2.y; ng[1][3] = p2.w;
         }

@@ -73,9 +73,9 @@ struct Lay {
     int64_t o_gT;   // [sym_cnt] the part of dE/dv (same for both streams) that is a correlation of v_a + v_b (matrix-core ELBO kernels)
     int64_t o_cxH, o_cxh1, o_part_cx, o_tot_cx;
     // run kernel (k_elbo_cx3): cx_split = 1, every wave owns a run of cx_rl symbols of one phase.  dE/d(moments) then lives in
-    // three arrays of per-symbol 4-vectors at o_gpk, [3][sym_cnt][4]: [0] and [1] the gradients of (mean_a, mean_b, var_a, var_b)
-    // from the windows of phase 0 and of phase 1 (S = 2), [2] = (3rd-moment gradients a, b; the part of the variance gradient
-    // that is a correlation of v_a + v_b; the 4th-cumulant gradient) from k_g2_cx; the per-symbol backward adds them up
+    // S + 1 arrays of per-symbol 4-vectors at o_gpk, [S + 1][sym_cnt][4]: [r] the gradients of (mean_a, mean_b, var_a, var_b)
+    // from the windows of phase r, [S] = (3rd-moment gradients a, b; the part of the variance gradient that is a
+    // correlation of v_a + v_b; the 4th-cumulant gradient) from k_g2_cx; the per-symbol backward adds them up
     int cx_split;
     // real model on the run kernel: the quadrature stream is identically zero (its moment planes are allocated and zero-filled by the
     // soft demapper, its samples read as zero) and the kernel adds the terms of the diagonal quirk (dq = diag(h2), d = 2 diag(h2))
