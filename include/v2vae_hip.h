@@ -84,6 +84,10 @@ typedef struct v2vae_problem {
 #define V2VAE_SCAL_LOSS 2   /* KL + W log E (:919) */
 #define V2VAE_SCAL_LAMBDA 3 /* W / E */
 #define V2VAE_SCAL_W 4      /* number of windows W = n_glob - L + 1 */
+#define V2VAE_SCAL_BAD_STEPS 5 /* failure detection (the reference has none on this path: a non-finite loss just propagates,
+                                  lib/real_equalization.py:919): running count of steps whose E was not a positive finite number or
+                                  whose KL term was not finite, since the caller last zeroed the block.  The library only ever adds
+                                  to it (v2vae_train_step_static starts every call from a zeroed block: there it is 0 or 1) */
 #define V2VAE_SCAL_COUNT 8
 
 /* Bytes of workspace the calls below need for this problem (0 if the problem is invalid). */

@@ -313,3 +313,55 @@ def test_complex_classes_fit_and_manual_step_agree():
         assert rel(b._pack, a._pack.cpu().numpy()) < 1e-6
         q = a.estimate_symbol_probs(rx)
         assert q.shape == (8, 3 * B) and np.allclose(q[:4].sum(0), 1, atol=1e-5) and np.allclose(q[4:].sum(0), 1, atol=1e-5)
+
+
+def test_failure_detection_counts_steps_with_a_non_finite_or_non_positive_exponent_term():
+    """The scalar block keeps a running count of steps whose E was not a positive finite number (V2VAE_SCAL_BAD_STEPS): zero on
+    healthy steps, incremented when the samples carry a NaN - through the per-batch sequence and through the on-chip fit
+    kernel.  The reference has no check on this path (lib/real_equalization.py:919: the NaN loss just propagates)."""
+    from volterra_vae_amd.ops import PersistentFit, Plan
+    from volterra_vae_amd.synth import nonlinear_isi, pam_constellation
+    from volterra_vae_amd import _lib
+    dev = torch.device("cuda")
+    S, B, L, l1, l2, M = 2, 500, 15, 25, 25, 4
+    rx, _ = nonlinear_isi(3 * B, pam_constellation(M), S, 16.0, np.random.default_rng(4))
+    y = torch.from_numpy(rx).float().to(dev).view(1, -1).contiguous()
+    plan = Plan(ns=1, sps=S, l1=l1, pad1=l1 // 2, l2=l2, L=L, C_levels=M, n_glob=B * S, device=dev)
+    n = plan.sizes
+    def fresh():
+        p = torch.zeros(sum(n), device=dev)
+        p[L // 2] = 1.0; p[n[0] + n[1] + l1 // 2] = 1.0; p[-M:] = 1.0
+        return p
+    params = fresh()
+    grads, m, v, vm = (torch.zeros_like(params) for _ in range(4))
+    lv = torch.arange(-(M - 1), M, 2, dtype=torch.float32, device=dev).view(1, -1)
+    prior = torch.full_like(lv, 1.0 / M)
+    nv = torch.tensor([0.05], device=dev)
+    xhat = torch.empty((1, B), device=dev)
+    loss = torch.zeros(1, device=dev)
+    kw = dict(levels=lv, prior=prior, params=params, grads=grads, adam_m=m, adam_v=v, adam_vmax=vm, noise_var=nv, xhat=xhat,
+              loss_out=loss, lr=5e-3)
+    plan.train_step(y=y[:, :B * S].contiguous(), step=1, **kw)
+    assert plan.bad_steps() == 0 and bool(torch.isfinite(loss).all())
+    ybad = y[:, B * S:2 * B * S].clone()
+    ybad[0, 77] = float("nan")
+    plan.train_step(y=ybad, step=2, **kw)
+    assert plan.bad_steps() == 1
+    # on-chip fit kernel: three batches, the second one poisoned
+    pf = PersistentFit(ns=1, sps=S, l1=l1, pad1=l1 // 2, l2=l2, L=L, C_levels=M, batch_symbols=B, n_models=1, device=dev)
+    assert pf.on_chip
+    p2 = fresh().view(1, -1)
+    g2, m2, v2, vm2 = (torch.zeros_like(p2) for _ in range(4))
+    nv2 = torch.tensor([0.05], device=dev)
+    y3 = y.clone()
+    pf.run(y=y3, levels=lv, prior=prior, params=p2, grads=g2, adam_m=m2, adam_v=v2, adam_vmax=vm2, noise_var=nv2, lrs=[5e-3] * 3)
+    torch.cuda.synchronize()
+    assert int(pf.scal[0, _lib.SCAL_BAD_STEPS].item()) == 0
+    y3[0, B * S + 5] = float("nan")
+    p2.copy_(fresh().view(1, -1))
+    for t in (g2, m2, v2, vm2):
+        t.zero_()
+    nv2.fill_(0.05)
+    pf.run(y=y3, levels=lv, prior=prior, params=p2, grads=g2, adam_m=m2, adam_v=v2, adam_vmax=vm2, noise_var=nv2, lrs=[5e-3] * 3)
+    torch.cuda.synchronize()
+    assert int(pf.scal[0, _lib.SCAL_BAD_STEPS].item()) >= 1

@@ -36,7 +36,7 @@ def default_flags() -> int:
         (FLAG_REAL_MFMA if os.environ.get("V2VAE_REAL_MFMA") else 0)
 
 
-SCAL_E, SCAL_KL, SCAL_LOSS, SCAL_LAMBDA, SCAL_W, SCAL_COUNT = 0, 1, 2, 3, 4, 8
+SCAL_E, SCAL_KL, SCAL_LOSS, SCAL_LAMBDA, SCAL_W, SCAL_BAD_STEPS, SCAL_COUNT = 0, 1, 2, 3, 4, 5, 8
 
 
 class Problem(C.Structure):

@@ -325,6 +325,7 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
     for (int i = tid; i < o.total; i += RS_NT) sm[i] = 0.f;
     float nv = a.noise_var[model];
     double E = 0.0, KL = 0.0, loss = 0.0, lamd = 0.0;
+    int bad_steps = 0;   // batches whose E was not a positive finite number or whose KL was not finite (failure detection)
     const float w1 = (float)(1.0 - (double)a.beta1), w2 = (float)(1.0 - (double)a.beta2);
     const float* ym = a.y + (int64_t)model * a.y_model_stride;
     const float* levels = a.levels;
@@ -691,6 +692,7 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
         E = rs_block_sum(Eacc, s_dbl, tid);
         loss = KL + (double)W * log(E);
         lamd = (double)W / E;
+        if (!(E > 0.0) || !isfinite(E) || !isfinite(KL)) ++bad_steps;
         const float lam = (float)lamd;
 
         RS_STAMP(7);
@@ -916,6 +918,7 @@ __global__ __launch_bounds__(RS_NT) void k_fit_rs(Lay l, RsOff o, v2vae_fit_args
         double* sc = a.scal + (int64_t)model * V2VAE_SCAL_COUNT;
         sc[V2VAE_SCAL_E] = E; sc[V2VAE_SCAL_KL] = KL; sc[V2VAE_SCAL_LOSS] = loss; sc[V2VAE_SCAL_LAMBDA] = lamd;
         sc[V2VAE_SCAL_W] = (double)W;
+        sc[V2VAE_SCAL_BAD_STEPS] += (double)bad_steps;
     }
 }
 

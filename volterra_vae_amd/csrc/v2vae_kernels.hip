@@ -1388,10 +1388,13 @@ __global__ __launch_bounds__(NT) void k_reduce_scalars(Lay l, const float* __res
 
 __device__ __forceinline__ void d_finalize_scalars(const GridCtx gc, double W, double* __restrict__ scal) {
     if (threadIdx.x == 0 && gc.bid == 0) {
-        const double E = scal[V2VAE_SCAL_E];
-        scal[V2VAE_SCAL_LOSS] = scal[V2VAE_SCAL_KL] + W * log(E);
+        const double E = scal[V2VAE_SCAL_E], KL = scal[V2VAE_SCAL_KL];
+        scal[V2VAE_SCAL_LOSS] = KL + W * log(E);
         scal[V2VAE_SCAL_LAMBDA] = W / E;
         scal[V2VAE_SCAL_W] = W;
+        // failure detection: steps whose exponent term was not a positive finite number or whose KL term was not finite (the
+        // loss and every gradient of such a step are meaningless); a running count the caller reads when it next synchronises
+        if (!(E > 0.0) || !isfinite(E) || !isfinite(KL)) scal[V2VAE_SCAL_BAD_STEPS] += 1.0;
     }
 }
 

@@ -140,6 +140,11 @@ class Plan:
         self.ws[hi:hi + n].copy_(xhat.reshape(-1))
         self.ws[lo:lo + n].copy_(xlo.reshape(-1))
 
+    def bad_steps(self) -> int:
+        """Failure detection: how many steps on this plan had an exponent term E that was not a positive finite number or a
+        non-finite KL term since the plan was created (synchronises; the reference has no such check)."""
+        return int(self.scal[_lib.SCAL_BAD_STEPS].item())
+
     def gmoments_view(self):
         off = lib.v2vae_ws_offset_gmoments(C.byref(self.p))
         n = self.p.ns * 4 * self.p.sym_cnt
