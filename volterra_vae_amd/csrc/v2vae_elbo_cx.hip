@@ -535,7 +535,8 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
         } else {               // [[Hr, -Hi], [Hi, Hr]], row = the (stream, tap) that cx3_hw_slot puts on k-slot (s - NK, h)
             int ck, xk;
             cx3_hw_slot<NK>(s - NK, hh, &ck, &xk);
-            const float a = Hr[xk * 16 + yjj], b = Hi[xk * 16 + yjj];
+            // (doubled: the operand the chain takes from the registers is w / 2, see the per-tap algebra)
+            const float a = 2.f * Hr[xk * 16 + yjj], b = 2.f * Hi[xk * 16 + yjj];
             v = ck == 0 ? (cjj == 0 ? a : -b) : (cjj == 0 ? b : a);
         }
         s_A[idx] = v;
@@ -559,9 +560,13 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
     // (combined once at the end: the sums are linear).  16x16x4 MFMAs, four windows per k-step.
     f32x4 K1 = {0.f, 0.f, 0.f, 0.f}, K2 = K1, K3 = K1;
     f2 ghr[4], ghi[4], gdr[4], gdi[4];  // vector gradients of the tap pairs (2 p, 2 p + 1)
-    f2 cdr[4], cdi[4];                  // diagonal of the kernel at this lane's tap pairs (both passes of a slab use it)
+    f2 cdr[4], cdi[4], cdd[4];          // diagonal of the kernel at this lane's tap pairs (both passes of a slab use it), its squared modulus
 #pragma unroll
-    for (int p = 0; p < 4; ++p) { ghr[p] = 0.f; ghi[p] = 0.f; gdr[p] = 0.f; gdi[p] = 0.f; cdr[p] = C2(2, p); cdi[p] = C2(3, p); }
+    for (int p = 0; p < 4; ++p) {
+        ghr[p] = 0.f; ghi[p] = 0.f; gdr[p] = 0.f; gdi[p] = 0.f; cdr[p] = C2(2, p); cdi[p] = C2(3, p);
+        cdd[p] = REAL ? cdr[p] * cdr[p] : cdr[p] * cdr[p] + cdi[p] * cdi[p];
+        asm volatile("" : "+v"(cdd[p]));   // (kept in registers: recomputed per slab it costs two instructions per tap pair)
+    }
     double Eacc = 0.0;
 
     // ---- this wave's run: symbols [a, b) of phase r
@@ -710,9 +715,10 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
                 sd1v += dv * di;
                 const f2 z2 = zp * zp + zq * zq;
                 const f2 ca = dr * zp + di * zq, cb = dr * zq - di * zp;
-                vsv += Sv * z2 + 2.f * (ka * ca + kb * cb) + gs * (dr * dr + di * di);
-                al[p] = 2.f * (Sv * zp + ka * dr - kb * di);
-                be[p] = 2.f * (Sv * zq + ka * di + kb * dr);
+                vsv += Sv * z2 + 2.f * (ka * ca + kb * cb) + gs * cdd[p];
+                // (alpha, beta) / 2: the factor two rides in the constant operand of the H w product, which is exact
+                al[p] = Sv * zp + ka * dr - kb * di;
+                be[p] = Sv * zq + ka * di + kb * dr;
                 zP[p] = zp; zQ[p] = zq;
                 zz[p] = z2;
                 dvv[p] = dv;
@@ -730,6 +736,7 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
             if (REAL) sd0 = cx_sum_halves(sd0);
             if (own && h == 0) Eacc += (double)(e0 * e0 + e1 * e1 + vs + (REAL ? y0 * sd0 : 0.f));
             e0 *= mv; e1 *= mv;
+            const float E0 = 2.f * e0, E1 = 2.f * e1;   // masked and doubled once, instead of per tap pair
 
             STAMP(2);
             // ---- H w: k-slot (s, h) carries the (stream, tap) of cx3_hw_slot
@@ -762,17 +769,18 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
             //      (even tap, odd tap) pairs; lane m sums the eight pair rows at window m - even tap, and the odd taps' sums, which
             //      belong to the next symbol, move up one lane at the end.
             constexpr int ZV = 8 * 32, PB = ZV + 1;   // the zero vector of plane A; plane B starts behind it and ends in its own
+            const float mv2 = 2.f * mv;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const int pr = cx_kk(2 * p, h) >> 1;
                 const f2 zero2 = {0.f, 0.f};
                 const f2 zp = zP[p], zq = zQ[p], dr = cdr[p], di = REAL ? zero2 : cdi[p];
-                const f2 ed = 2.f * (e0 * dr + e1 * di);
-                const f2 da0 = (2.f * mv) * (e0 * zp + e1 * zq + f2{HW[2 * p], HW[2 * p + 1]});
+                const f2 ed = E0 * dr + E1 * di;
+                const f2 da0 = E0 * zp + (E1 * zq + mv2 * f2{HW[2 * p], HW[2 * p + 1]});
                 // (REAL: the gradients with respect to the quadrature moments are not read by anyone)
-                const f2 db0 = REAL ? zero2 : (2.f * mv) * (e1 * zp - e0 * zq + f2{HW[2 * p + 8], HW[2 * p + 9]});
-                f2 da1 = mv * (zz[p] + ed);
-                const f2 db1 = REAL ? zero2 : mv * (zz[p] - ed);
+                const f2 db0 = REAL ? zero2 : E1 * zp - (E0 * zq - mv2 * f2{HW[2 * p + 8], HW[2 * p + 9]});
+                f2 da1 = mv * zz[p] + ed;          // (E0, E1 carry the mask already)
+                const f2 db1 = REAL ? zero2 : mv * zz[p] - ed;
                 if (REAL) da1 += (mv * y0) * dr;
                 Bd[pr * 32 + i] = f32x4{da0.x, da0.y, db0.x, db0.y};
                 Bd[PB + pr * 32 + i] = f32x4{da1.x, da1.y, db1.x, db1.y};
@@ -820,12 +828,12 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
             for (int p = 0; p < 4; ++p) {
                 const int x = cx_kk(2 * p, h);
                 const f2 ma = mav[p], mb = mbv[p];
-                const f2 gr = 2.f * (e0 * ma + e1 * mb), gi = 2.f * (e1 * ma - e0 * mb);
-                ghr[p] += mo * (gr + al[p]);
-                ghi[p] += mo * (gi + be[p]);
-                gdr[p] += (mo * 2.f * e0) * dvv[p];
-                gdi[p] += (mo * 2.f * e1) * dvv[p];
-                const f2 t0 = mo * (gr + 2.f * al[p]), t1 = mo * (gi + 2.f * be[p]);
+                const f2 gr = E0 * ma + E1 * mb, gi = E1 * ma - E0 * mb;
+                ghr[p] += mo * (gr + 2.f * al[p]);
+                ghi[p] += mo * (gi + 2.f * be[p]);
+                gdr[p] += (mo * E0) * dvv[p];
+                gdi[p] += (mo * E1) * dvv[p];
+                const f2 t0 = mo * (gr + 4.f * al[p]), t1 = mo * (gi + 4.f * be[p]);
                 Tr[i * 17 + x] = t0.x;
                 Tr[i * 17 + x + 1] = t0.y;
                 if (!REAL) {   // (sigma is zero)
