@@ -53,6 +53,10 @@ extern "C" {
                                     per tile) instead of the run kernel (every wave on its own run of windows); 17 or 33 active
                                     taps: whole blocks of 16 taps (2 or 3) instead of 1 or 2 blocks plus one tap on the side */
 
+#define V2VAE_FLAG_F32_MATRIX 16 /* one or two samples per symbol, l2 <= 79: the equaliser backward (and, complex model with <= 16
+                                    active taps per phase, the H X product of the run ELBO kernel) on f32 matrix instructions
+                                    instead of bf16 ones in three-piece split arithmetic */
+
 typedef struct v2vae_problem {
     int32_t ns;      /* 1 or 2 */
     int32_t mode;    /* 0 real (bug-compatible with lib/real_equalization.py:869), 1 complex,

@@ -21,7 +21,7 @@ OK, EINVAL, EHALO, ELAUNCH, ESIZE = 0, -1, -2, -3, -4
 _ERR = {EINVAL: "invalid argument / unsupported shape", EHALO: "local sample or symbol range does not cover the halo",
         ELAUNCH: "HIP launch error", ESIZE: "problem exceeds the kernels' on-chip tiling limits"}
 
-FLAG_GENERIC, FLAG_EQ_MFMA_FWD, FLAG_ELBO_TILES, FLAG_REAL_MFMA = 1, 2, 4, 8
+FLAG_GENERIC, FLAG_EQ_MFMA_FWD, FLAG_ELBO_TILES, FLAG_REAL_MFMA, FLAG_F32_MATRIX = 1, 2, 4, 8, 16
 
 
 def default_flags() -> int:
@@ -33,7 +33,8 @@ def default_flags() -> int:
     return (FLAG_GENERIC if os.environ.get("V2VAE_FORCE_GENERIC") else 0) | \
         (FLAG_EQ_MFMA_FWD if os.environ.get("V2VAE_EQ_MFMA_FWD") else 0) | \
         (FLAG_ELBO_TILES if os.environ.get("V2VAE_ELBO_TILES") else 0) | \
-        (FLAG_REAL_MFMA if os.environ.get("V2VAE_REAL_MFMA") else 0)
+        (FLAG_REAL_MFMA if os.environ.get("V2VAE_REAL_MFMA") else 0) | \
+        (FLAG_F32_MATRIX if os.environ.get("V2VAE_F32_MATRIX") else 0)
 
 
 SCAL_E, SCAL_KL, SCAL_LOSS, SCAL_LAMBDA, SCAL_W, SCAL_BAD_STEPS, SCAL_COUNT = 0, 1, 2, 3, 4, 5, 8

@@ -9,6 +9,8 @@ namespace v2vae {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short bfx8 __attribute__((ext_vector_type(8)));   // eight bf16 values: one operand of a 16-deep bf16 matrix instruction
 
 // tap (within a block of 16) held in accumulator register q of lane half h of a 32x32 MFMA result
 typedef float f2 __attribute__((ext_vector_type(2)));

@@ -470,19 +470,32 @@ __global__ __launch_bounds__(NW * 64) void k_elbo_cx2(Lay l, const float* __rest
 // NK = k-steps of the H X and H w products: 16, or 13 when no phase has more than 13 active taps (the k index then runs over
 // [stream][13 taps] and three values of the H w operand change lane halves).
 // ------------------------------------------------------------------------------------------------------------
-// windows per strip: 192 with one or two phases; 96 with four samples per symbol, whose four per-phase tables leave the eight
-// wave areas less of the 160 KB
-__host__ __device__ constexpr int cx3_wt(int S) { return S <= 2 ? 192 : 96; }
+// H X on the bf16 matrix pipe in split arithmetic (complex model, one or two phases): every float is the exact sum of three
+// bf16 pieces (8 + 8 + 8 significand bits, by truncation), and the six piece products whose weight is not below 2^-24 of the
+// whole are accumulated in float by v_mfma_f32_32x32x16_bf16 - twelve matrix instructions of 32 cycles instead of thirteen of
+// 64, which moreover leave the vector pipe free while they run (an f32 matrix instruction holds it for its 64 cycles).  The
+// means are split once per symbol when they are staged, the table once per workgroup.
+__host__ __device__ constexpr bool cx3_bfx(int S, bool REAL) { return !REAL && S <= 2; }
+// windows per strip: 192 with one or two phases (128 where the bf16 pieces of the means take their share of the wave's area);
+// 96 with four samples per symbol, whose four per-phase tables leave the eight wave areas less of the 160 KB
+__host__ __device__ constexpr int cx3_wt(int S, bool BFX) { return S <= 2 ? (BFX ? 128 : 192) : 96; }
 // staged symbols per strip (16 used beyond the windows; 32 keeps the gradient update of a slab, 64 lanes wide, inside the arrays)
-__host__ __device__ constexpr int cx3_ms(int S) { return cx3_wt(S) + 32; }
+__host__ __device__ constexpr int cx3_ms(int S, bool BFX) { return cx3_wt(S, BFX) + 32; }
 constexpr int CX3_NW = 8;                   // waves per workgroup
 constexpr int CX3_ADB = 16 * 32 + 4;        // 4-vectors of the anti-diagonal buffer (two planes of 8 tap-pair rows of 32 windows, a zero vector behind each)
 // floats of one wave's private LDS: 7 moment planes, the per-symbol gradient 4-vectors, the anti-diagonal buffer (which the
-// transposing buffer of the rho / sigma rows shares: the two are used one after the other within a slab)
-__host__ __device__ constexpr int cx3_wave_f(int S) { return 7 * cx3_ms(S) + 4 * cx3_ms(S) + 4 * CX3_ADB; }
+// transposing buffer of the rho / sigma rows shares: the two are used one after the other within a slab), and with BFX the
+// bf16 pieces of the means [2 streams][3 pieces][MS] (two bytes each)
+__host__ __device__ constexpr int cx3_wave_f(int S, bool BFX) {
+    return 7 * cx3_ms(S, BFX) + 4 * cx3_ms(S, BFX) + 4 * CX3_ADB + (BFX ? 3 * cx3_ms(S, BFX) : 0);
+}
+// floats of one phase's constant operands: f32 images [steps][64] (H X and H w; H w alone with BFX), and with BFX the bf16
+// image of the H X table [3 pieces][2 chunks][64 lanes][8]
+__host__ __device__ constexpr int cx3_tab_f32(int NK, bool BFX) { return (BFX ? NK : 2 * NK) * 64; }
+constexpr int CX3_TAB_BF = 3 * 2 * 64 * 8 / 2;
 
-__host__ __device__ constexpr int cx3_lds_floats(int S, int NK) {
-    return S * 2 * NK * 64 + S * 64 + CX3_NW * cx3_wave_f(S);
+__host__ __device__ constexpr int cx3_lds_floats(int S, int NK, bool BFX) {
+    return S * cx3_tab_f32(NK, BFX) + S * 64 + (BFX ? S * CX3_TAB_BF : 0) + CX3_NW * cx3_wave_f(S, BFX);
 }
 
 // REAL: the real model (one stream).  Everything that is identically zero with a zero quadrature stream is a compile-time zero in
@@ -493,16 +506,22 @@ __host__ __device__ constexpr int cx3_lds_floats(int S, int NK) {
 // zero-filled by the soft demapper, the imaginary planes of the tables are zero - and the three terms of the reference's
 // diagonal quirk (lib/real_equalization.py:869: the mean uses diag(h2) where the second moment uses the diagonal d = 2 diag(h2) of
 // the symmetrised kernel) are added: with T_n = y'_n sum_x v_{n+x} d_x,  E += T_n,  dE/dv_{n+x} += y'_n d_x,  dE/dd_x += y'_n v_{n+x}.
-template <int S, int NK, bool REAL>
+template <int S, int NK, bool REAL, bool BFX>
 __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __restrict__ y, float* __restrict__ ws) {
     extern __shared__ __align__(16) float sm[];
-    constexpr int WT = cx3_wt(S), MS = cx3_ms(S), CX3_WAVE_F = cx3_wave_f(S), TP = CX_TP, NW = CX3_NW;
+    static_assert(!BFX || cx3_bfx(S, REAL), "the split-bf16 H X product serves the complex model with one or two phases");
+    constexpr int WT = cx3_wt(S, BFX), MS = cx3_ms(S, BFX), CX3_WAVE_F = cx3_wave_f(S, BFX), TP = CX_TP, NW = CX3_NW;
     constexpr int NWP = NW / S;
     constexpr int CX3_NT = NW * 64;
     static_assert(NK == 16 || NK == 13, "k-step counts with an operand schedule");
-    float* s_A = sm;                           // [S][2 NK][64]  A operands: steps 0..NK-1 H X, NK..2NK-1 H w
-    float* s_c = s_A + S * 2 * NK * 64;        // [S][4][16]     h1r, h1i, diag Hr, diag Hi
-    float* s_W = s_c + S * 64;                 // [NW][CX3_WAVE_F]
+    constexpr int NA = cx3_tab_f32(NK, BFX) / 64;   // f32 A-operand steps per phase
+    constexpr int HW0 = BFX ? 0 : NK;          // first step of the H w operands
+    float* s_A = sm;                           // [S][NA][64]    A operands: steps 0..NK-1 H X (not with BFX), then NK steps of H w
+    float* s_c = s_A + S * NA * 64;            // [S][4][16]     h1r, h1i, diag Hr, diag Hi
+    // BFX: the H X table in bf16 pieces, [S][3 pieces][2 chunks][64 lanes][8]: lane (row, half), element j of chunk c is the
+    // entry of k-slot (stream = half, tap = 8 c + j)
+    unsigned short* s_Ab = reinterpret_cast<unsigned short*>(s_c + S * 64);
+    float* s_W = s_c + S * 64 + (BFX ? S * CX3_TAB_BF : 0);   // [NW][CX3_WAVE_F]
     __shared__ double dred[CX3_NT / 64];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -513,6 +532,7 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
     f32x4* Bd = G4 + MS;                       // [ADB] anti-diagonal buffer
     float* Tr = reinterpret_cast<float*>(Bd);  // [32 windows][17] rho rows and, after them, sigma rows: the transposing buffers of
     float* Ts = Tr + 32 * 17;                  // the dE/dH accumulation, in the same memory as the anti-diagonal buffer
+    unsigned short* Xb = reinterpret_cast<unsigned short*>(Bd + CX3_ADB);   // BFX: [2 streams][3 pieces][MS] bf16 pieces of the means
     static_assert(2 * 32 * 17 <= 4 * 16 * 32 && S * CX_REC <= CX3_WAVE_F, "shared regions");
     const int i16 = lane & 15, kq = lane >> 4;
     const float* __restrict__ mom = ws + l.o_mom;
@@ -520,8 +540,8 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
 
     // ---- constants of every phase into LDS (compile-time trip count: unrolled, so that the loads of all passes are in flight together)
 #pragma unroll
-    for (int idx = tid; idx < S * 2 * NK * 64; idx += CX3_NT) {
-        const int ln = idx & 63, s = (idx >> 6) % (2 * NK), rr = idx / (2 * NK * 64);
+    for (int idx = tid; idx < S * NA * 64; idx += CX3_NT) {
+        const int ln = idx & 63, s = (idx >> 6) % NA + (BFX ? NK : 0), rr = idx / (NA * 64);
         const int jj = ln & 31, hh = ln >> 5, cjj = jj >> 4, yjj = jj & 15;
         const float* Hr = ws + l.o_cxH + (size_t)(rr * 2 + 0) * 256;
         const float* Hi = ws + l.o_cxH + (size_t)(rr * 2 + 1) * 256;
@@ -541,6 +561,28 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
         }
         s_A[idx] = v;
     }
+    if (BFX) {
+#pragma unroll
+        for (int idx = tid; idx < S * 2 * 64 * 8; idx += CX3_NT) {
+            const int j = idx & 7, ln = (idx >> 3) & 63, c = (idx >> 9) & 1, rr = idx >> 10;
+            const int jj = ln & 31, ck = ln >> 5, cjj = jj >> 4, yjj = jj & 15, xk = 8 * c + j;
+            const float* Hr = ws + l.o_cxH + (size_t)(rr * 2 + 0) * 256;
+            const float* Hi = ws + l.o_cxH + (size_t)(rr * 2 + 1) * 256;
+            float a = Hr[xk * 16 + yjj], b = Hi[xk * 16 + yjj];
+            // NK = 13: output row 13 (no such tap) computes the first-order term h1 . X of the window instead
+            if (NK == 13 && yjj == 13) { a = ws[l.o_cxh1 + (rr * 2 + 0) * 16 + xk]; b = ws[l.o_cxh1 + (rr * 2 + 1) * 16 + xk]; }
+            float v = ck == 0 ? (cjj == 0 ? a : b) : (cjj == 0 ? -b : a);
+            if (xk >= NK) v = 0.f;
+            const unsigned b1 = __float_as_uint(v) & 0xFFFF0000u;
+            const float r1 = v - __uint_as_float(b1);
+            const unsigned b2 = __float_as_uint(r1) & 0xFFFF0000u;
+            const float r2 = r1 - __uint_as_float(b2);
+            unsigned short* d = s_Ab + ((size_t)(rr * 3) * 2 + c) * 512 + ln * 8 + j;
+            d[0] = (unsigned short)(b1 >> 16);
+            d[2 * 512] = (unsigned short)(b2 >> 16);
+            d[4 * 512] = (unsigned short)(__float_as_uint(r2) >> 16);
+        }
+    }
     for (int idx = tid; idx < S * 64; idx += CX3_NT) {
         const int rr = idx / 64, q = (idx >> 4) & 3, x = idx & 15;
         const float* Hr = ws + l.o_cxH + (size_t)(rr * 2 + 0) * 256;
@@ -548,7 +590,8 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
         s_c[idx] = q == 0 ? ws[l.o_cxh1 + (rr * 2 + 0) * 16 + x] : q == 1 ? ws[l.o_cxh1 + (rr * 2 + 1) * 16 + x]
                  : q == 2 ? Hr[x * 16 + x] : Hi[x * 16 + x];
     }
-    const float* Aop = s_A + (size_t)r * 2 * NK * 64 + lane;
+    const float* Aop = s_A + (size_t)r * NA * 64 + lane;
+    const u32x4* Abf = reinterpret_cast<const u32x4*>(s_Ab) + (size_t)r * 6 * 64 + lane;   // [piece][chunk][64]
     const float* cst = s_c + r * 64 + 4 * h;
     __syncthreads();
 
@@ -602,6 +645,16 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
         float* d = stg + e0 + i;
         if (i >= jmin) {
             d[h * MS] = pm[0];                                  // mean_a | mean_b
+            if (BFX) {   // and its three bf16 pieces (exact: 8 + 8 + 8 significand bits by truncation)
+                const unsigned b1 = __float_as_uint(pm[0]) & 0xFFFF0000u;
+                const float r1 = pm[0] - __uint_as_float(b1);
+                const unsigned b2 = __float_as_uint(r1) & 0xFFFF0000u;
+                const float r2 = r1 - __uint_as_float(b2);
+                unsigned short* x = Xb + h * 3 * MS + e0 + i;
+                x[0] = (unsigned short)(b1 >> 16);
+                x[MS] = (unsigned short)(b2 >> 16);
+                x[2 * MS] = (unsigned short)(__float_as_uint(r2) >> 16);
+            }
             d[(2 + h) * MS] = h ? ov - pm[1] : pm[1] + ov;      // v_a + v_b | v_a - v_b
             d[(4 + h) * MS] = pm[2];                            // 3rd central moments
             if (h == 0) d[6 * MS] = pm[3] + og;                 // g_a + g_b
@@ -617,10 +670,13 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
         {
             f32x4 carry = {0.f, 0.f, 0.f, 0.f};
             float c0 = 0.f, c1 = 0.f;
+            unsigned cw = 0;
+            unsigned* Xw = reinterpret_cast<unsigned*>(Xb);   // (pairs of bf16 pieces)
             if (!first) {
                 if (lane < 16) carry = G4[WT + lane];
                 c0 = stg[(lane >> 4) * MS + WT + (lane & 15)];
                 if (lane < 48) c1 = stg[(4 + (lane >> 4)) * MS + WT + (lane & 15)];
+                if (BFX && lane < 48) cw = Xw[(lane >> 3) * (MS / 2) + WT / 2 + (lane & 7)];
             }
             __builtin_amdgcn_wave_barrier();
             for (int e = lane; e < MS; e += 64) G4[e] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -633,6 +689,7 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
             } else {
                 stg[(lane >> 4) * MS + (lane & 15)] = c0;
                 if (lane < 48) stg[(4 + (lane >> 4)) * MS + (lane & 15)] = c1;
+                if (BFX && lane < 48) Xw[(lane >> 3) * (MS / 2) + (lane & 7)] = cw;
             }
         }
         if (first) fetch32(ts + 16);
@@ -659,6 +716,32 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
             __builtin_amdgcn_wave_barrier();
 
             f32x16 U = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (BFX) {
+                // B operand: k-slot (chunk c, lane half h, element j) = (stream h, tap 8 c + j), i.e. the 16 consecutive bf16
+                // of stream h from staged symbol tsl + i on.  Nine aligned words cover them; an odd window shifts by one piece.
+                // (one opaque LDS address register: the 27 words sit within the offset field of the reads)
+                typedef const unsigned __attribute__((address_space(3))) * lword_p;
+                lword_p xw = (lword_p)(reinterpret_cast<const unsigned*>(Xb) + h * 3 * (MS / 2) + ((tsl + i) >> 1));
+                asm volatile("" : "+v"(xw));
+                const unsigned sh = (i & 1) * 16;
+                u32x4 d[3][2];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    unsigned w[9];
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) w[q] = xw[p * (MS / 2) + q];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) d[p][q >> 2][q & 3] = __builtin_amdgcn_alignbit(w[q + 1], w[q], sh);
+                }
+                // table piece x operand piece, smallest products first: (1,3) (2,2) (3,1) (1,2) (2,1) (1,1)
+                constexpr int TP6[6] = {0, 1, 2, 0, 1, 0}, DP6[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+                        U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bfx8, Abf[(TP6[k] * 2 + c) * 64]),
+                                                                    __builtin_bit_cast(bfx8, d[DP6[k]][c]), U, 0, 0, 0);
+            } else {
 #pragma unroll
             for (int s = 0; s < NK; ++s) {
                 // k = 2 s + h over [stream][NK taps]
@@ -676,6 +759,7 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
             for (int s = 0; s < NK; ++s) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
             }
 
             STAMP(1);
@@ -744,21 +828,21 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
             if (NK == 16) {
 #pragma unroll
                 for (int s = 0; s < (REAL ? 8 : 16); ++s)   // (REAL: beta is zero)
-                    HW = MFMA32(Aop[(NK + s) * 64], s < 8 ? al[(s & 7) >> 1][s & 1] : be[(s & 7) >> 1][s & 1], HW);
+                    HW = MFMA32(Aop[(HW0 + s) * 64], s < 8 ? al[(s & 7) >> 1][s & 1] : be[(s & 7) >> 1][s & 1], HW);
             } else {
                 // accumulator slots q = 0..4 of either lane half hold valid taps (0-3, 8 | 4-7, 12): ten steps take them as they
                 // are; taps 9, 10, 11 (slots 5-7 of the lower half, whose upper-half partners 13-15 do not exist) take three
                 // steps in which the upper half supplies the lower half's beta value, moved over by a lane-half swap
 #pragma unroll
-                for (int s = 0; s < 5; ++s) HW = MFMA32(Aop[(NK + s) * 64], al[s >> 1][s & 1], HW);
+                for (int s = 0; s < 5; ++s) HW = MFMA32(Aop[(HW0 + s) * 64], al[s >> 1][s & 1], HW);
 #pragma unroll
-                for (int s = 0; s < (REAL ? 0 : 5); ++s) HW = MFMA32(Aop[(NK + 5 + s) * 64], be[s >> 1][s & 1], HW);
+                for (int s = 0; s < (REAL ? 0 : 5); ++s) HW = MFMA32(Aop[(HW0 + 5 + s) * 64], be[s >> 1][s & 1], HW);
 #pragma unroll
                 for (int s = 5; s < 8; ++s) {
                     float x = al[s >> 1][s & 1], z = be[s >> 1][s & 1];
                     if (REAL) x = h ? 0.f : x;   // (alpha of lanes 0-31 | beta = 0)
                     else asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(z));   // x = (alpha of lanes 0-31 | beta of lanes 0-31)
-                    HW = MFMA32(Aop[(NK + 5 + s) * 64], x, HW);
+                    HW = MFMA32(Aop[(HW0 + 5 + s) * 64], x, HW);
                 }
             }
 
@@ -1270,15 +1354,14 @@ int launch_elbo_cx(const Lay& l, const float* y, float* ws, hipStream_t st) {
         return launch_cx(k_elbo_cx2<2, 8>, l, l.lds_cx, y, ws, st);
     }
     const bool k13 = l.LE <= 13;
-    const int lds = cx3_lds_floats(l.S, k13 ? 13 : 16) * 4;
-    if (l.cx_real) {
-        if (l.S == 4) return k13 ? launch_cx(k_elbo_cx3<4, 13, true>, l, lds, y, ws, st) : launch_cx(k_elbo_cx3<4, 16, true>, l, lds, y, ws, st);
-        if (l.S == 1) return k13 ? launch_cx(k_elbo_cx3<1, 13, true>, l, lds, y, ws, st) : launch_cx(k_elbo_cx3<1, 16, true>, l, lds, y, ws, st);
-        return k13 ? launch_cx(k_elbo_cx3<2, 13, true>, l, lds, y, ws, st) : launch_cx(k_elbo_cx3<2, 16, true>, l, lds, y, ws, st);
-    }
-    if (l.S == 4) return k13 ? launch_cx(k_elbo_cx3<4, 13, false>, l, lds, y, ws, st) : launch_cx(k_elbo_cx3<4, 16, false>, l, lds, y, ws, st);
-    if (l.S == 1) return k13 ? launch_cx(k_elbo_cx3<1, 13, false>, l, lds, y, ws, st) : launch_cx(k_elbo_cx3<1, 16, false>, l, lds, y, ws, st);
-    return k13 ? launch_cx(k_elbo_cx3<2, 13, false>, l, lds, y, ws, st) : launch_cx(k_elbo_cx3<2, 16, false>, l, lds, y, ws, st);
+    const bool bfx = cx3_bfx(l.S, l.cx_real) && !(l.flags & V2VAE_FLAG_F32_MATRIX);
+    const int lds = cx3_lds_floats(l.S, k13 ? 13 : 16, bfx) * 4;
+#define V2VAE_CX3(SS, RR, BB) (k13 ? launch_cx(k_elbo_cx3<SS, 13, RR, BB>, l, lds, y, ws, st) : launch_cx(k_elbo_cx3<SS, 16, RR, BB>, l, lds, y, ws, st))
+    if (l.cx_real) return l.S == 4 ? V2VAE_CX3(4, true, false) : l.S == 1 ? V2VAE_CX3(1, true, false) : V2VAE_CX3(2, true, false);
+    if (l.S == 4) return V2VAE_CX3(4, false, false);
+    if (bfx) return l.S == 1 ? V2VAE_CX3(1, false, true) : V2VAE_CX3(2, false, true);
+    return l.S == 1 ? V2VAE_CX3(1, false, false) : V2VAE_CX3(2, false, false);
+#undef V2VAE_CX3
 }
 
 // what needs only the moments and runs right after the soft demapper: lagged products of s = v_a + v_b, and the gradients

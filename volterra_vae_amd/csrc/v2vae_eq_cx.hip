@@ -18,6 +18,7 @@
 namespace v2vae {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 // Sample tile from global sample g0 on, the two streams INTERLEAVED ([tile_len][2]: one 8-byte LDS read gives both parts of
@@ -174,6 +175,238 @@ __global__ __launch_bounds__(NT, NB16 <= 3 ? 4 : 2) void k_eq_bwd_cx(Lay l, cons
     for (int e = tid; e < 2 * LD * LD; e += NT) rec[e] = img[e];
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The same sums on the bf16 matrix pipe in split arithmetic (one or two samples per symbol).  An f32 matrix instruction
+// holds the SIMD's vector pipe for all of its cycles and runs at the vector rate; a bf16 one runs at sixteen times that rate
+// and leaves the vector pipe free.  Every float is the exact sum of three bf16 pieces (8 + 8 + 8 significand bits, by
+// truncation); the six piece products whose weight is not below 2^-24 of the whole, accumulated in float by
+// v_mfma_f32_16x16x32_bf16 (32 symbols per instruction), give the product to float accuracy.
+//   B operand (columns = lags, k = symbols): the samples themselves.  They are split once per tile when it is staged, into
+//   planes [copy][parity][piece plane][word] of bf16 PAIRS: the eight symbols a lane needs for its lag are eight consecutive
+//   elements of one parity plane (sample index = symbol * S + const), and the copy whose pairs start at the odd elements
+//   serves the lags whose first element is odd, so that an operand is four aligned consecutive words.
+//   A operand (rows = lags, k = symbols): rho = g0 Ya + g1 Yb, sigma = g1 Ya - g0 Yb of the lane's lag and eight symbols,
+//   formed in float from the float tile and split in registers (plain vector instructions: they run beside the matrix pipe).
+//   dK_r = sum rho^T Ya + sigma^T Yb,  dK_i = sum sigma^T Ya + (-rho)^T Yb: four products of 6 matrix instructions per
+//   16x16 block pair and 32 symbols.
+// ------------------------------------------------------------------------------------------------------------
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short bfx8 __attribute__((ext_vector_type(8)));
+#define MFMA16BF(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bfx8, (a)), __builtin_bit_cast(bfx8, (b)), (c), 0, 0, 0)
+
+// the three bf16 pieces of x as the high halves of three words (low halves of the first two are zero)
+__device__ __forceinline__ void bf_split3(float x, unsigned* p1, unsigned* p2, unsigned* p3) {
+    const unsigned b1 = __float_as_uint(x) & 0xFFFF0000u;
+    const float r1 = x - __uint_as_float(b1);
+    const unsigned b2 = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(b2);
+    *p1 = b1; *p2 = b2; *p3 = __float_as_uint(r2);
+}
+// (high half of lo, high half of hi) as one word of two bf16
+__device__ __forceinline__ unsigned bf_pack_hi(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
+// Words between the (copy, parity) regions of the planes of bf16 pairs: NPL piece planes and a pad of eight words.  The lanes
+// of one 4-byte read (32 banks of four bytes) cover about nine consecutive words in each of the four regions, so the regions are
+// put eight banks apart.
+template <bool REAL> constexpr int eqbf_rs() { return (REAL ? 3 : 6) * EQBF_NWD + 8; }
+
+// Sample tile from global sample g0 on, the two streams INTERLEAVED ([tile_len][2] floats: the A side forms rho and sigma from
+// them), and its bf16 pieces in the planes Yh (the B side).  Piece planes of a (copy, parity): piece dp of stream c (0: Ya,
+// 1: Yb) is plane 2 dp + c (the two streams of a piece side by side: one address register reaches both), dp alone for the
+// real model.  A tile that lies inside both the global sequence and the local sample block (all but the first and last few) is
+// copied without per-element checks.
+template <int SS, bool REAL>
+__device__ __forceinline__ void eqbf_load_tile(const Lay& l, const float* __restrict__ y, int64_t g0, float* tile,
+                                               unsigned short* Yh) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    constexpr int NPL = REAL ? 3 : 6, nwd = EQBF_NWD, RS = eqbf_rs<REAL>();
+    const int tl = l.tile_len;
+    const int64_t loc0 = g0 - l.y_lo;
+    const bool inside = g0 >= 0 && g0 + tl <= l.n_glob && loc0 >= 0 && loc0 + tl <= l.y_len;   // uniform
+    const float* __restrict__ sa = y + loc0;
+    const float* __restrict__ sb = REAL ? sa : y + l.y_stride + loc0;
+    f2* dst = reinterpret_cast<f2*>(tile);
+    auto put = [&](int i, f2 v) {
+        dst[i] = v;
+        const int e = SS == 1 ? i : i >> 1, par = SS == 1 ? 0 : i & 1;
+        unsigned pc[6];
+        if (REAL) bf_split3(v.x, &pc[0], &pc[1], &pc[2]);
+        else { bf_split3(v.x, &pc[0], &pc[2], &pc[4]); bf_split3(v.y, &pc[1], &pc[3], &pc[5]); }
+        // copy 0: element e is half e & 1 of word e >> 1, i.e. halfword e; copy 1 (pairs start at the odd elements): halfword e - 1
+        unsigned short* d0 = Yh + 2 * ((0 * SS + par) * RS) + e;
+        unsigned short* d1 = Yh + 2 * ((1 * SS + par) * RS) + e - 1;
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+            d0[2 * pl * nwd] = (unsigned short)(pc[pl] >> 16);
+            if (e >= 1) d1[2 * pl * nwd] = (unsigned short)(pc[pl] >> 16);
+        }
+    };
+    if (inside) {
+        // four samples per thread requested before the first is written (one memory latency per tile, not one per sample)
+        for (int i0 = threadIdx.x; i0 < tl; i0 += 4 * NT) {
+            f2 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + k * NT;
+                v[k] = i < tl ? f2{sa[i], REAL ? 0.f : sb[i]} : f2{0.f, 0.f};
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + k * NT;
+                if (i < tl) put(i, v[k]);
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < tl; i += NT) {
+            const int64_t g = g0 + i, loc = loc0 + i;
+            const bool in = g >= 0 && g < l.n_glob && loc >= 0 && loc < l.y_len;
+            put(i, in ? f2{sa[i], REAL ? 0.f : sb[i]} : f2{0.f, 0.f});
+        }
+    }
+}
+
+// LDS (floats): sample tile [tile_len][2] | (g0, g1) per symbol [EQ_TB] | constant (1, 0) samples [64 S][2] | planes of bf16
+// pairs [2 copies][S parities] regions of [NPL][EQBF_NWD] words (+ pad) | one constant region (lag columns from l2 on: Ya
+// pieces (1, 0, 0), Yb pieces 0)
+template <int NB16, int SS, bool REAL>
+__global__ __launch_bounds__(NT, NB16 <= 2 ? 4 : NB16 == 3 ? 3 : 2) void k_eq_bwd_bf(Lay l, const float* __restrict__ y, const float* __restrict__ gx,
+                                                                  float* __restrict__ ws) {
+    constexpr int NBLK = NB16 * (NB16 + 1) / 2, LD = 16 * NB16, S = SS, NPL = REAL ? 3 : 6, nwd = EQBF_NWD, RS = eqbf_rs<REAL>();
+    static_assert(SS == 1 || SS == 2, "parity planes for one or two samples per symbol");
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef const unsigned __attribute__((address_space(3))) * lword_p;
+    extern __shared__ __align__(16) float sm[];
+    float* tile = sm;
+    const int ntl = (2 * l.tile_len + 3) & ~3;
+    f2* g2 = reinterpret_cast<f2*>(sm + ntl);
+    const int o_ones = ntl + 2 * EQ_TB;
+    unsigned* Yw = reinterpret_cast<unsigned*>(sm + o_ones + 128 * S);
+    unsigned* Yc = Yw + 2 * S * RS;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int i16 = lane & 15, kq = lane >> 4;
+    f32x4 Ar[NBLK], Ai[NBLK];
+#pragma unroll
+    for (int q = 0; q < NBLK; ++q)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { Ar[q][g] = 0.f; Ai[q][g] = 0.f; }
+    for (int idx = tid; idx < 128 * S; idx += NT) sm[o_ones + idx] = (idx & 1) ? 0.f : 1.f;
+    for (int idx = tid; idx < 2 * S * RS; idx += NT) Yw[idx] = 0u;
+    for (int idx = tid; idx < RS; idx += NT) Yc[idx] = idx < nwd ? 0x3F803F80u : 0u;
+    // per-lane operand positions.  A side: the float samples of symbols (wave base + 8 kq + k) at this lane's lag of block ib.
+    // B side: four words from `pb` on (+ 16 words per 32 symbols) in each of the NPL planes of the lane's (copy, parity).
+    const f2* pa[NB16];
+    lword_p pb[NB16];
+    {
+        const int base0 = (wv * 64 + 8 * kq) * S + l.hl + l.p2;
+#pragma unroll
+        for (int ib = 0; ib < NB16; ++ib) {
+            const int j = 16 * ib + i16;
+            pa[ib] = reinterpret_cast<const f2*>(sm + (j >= l.l2 ? o_ones : 2 * (base0 - j)));
+            const int c = l.hl + l.p2 - j;                          // sample index of symbol 0 of the tile at this lag
+            const int off = S == 1 ? c : c >> 1, par = S == 1 ? 0 : c & 1;
+            pb[ib] = (lword_p)(j >= l.l2 ? Yc : Yw + ((off & 1) * S + par) * RS + (32 * wv + 4 * kq + (off >> 1)));
+        }
+    }
+    for (int t = blockIdx.x; t < l.ntile_eq; t += gridDim.x) {
+        const int64_t b0 = l.own_lo + (int64_t)t * EQ_TB;
+        const int64_t rem = l.own_lo + l.own_cnt - b0;
+        const int nbs = rem < EQ_TB ? (int)rem : EQ_TB;
+        __syncthreads();
+        eqbf_load_tile<SS, REAL>(l, y, b0 * l.S - l.hl, tile, reinterpret_cast<unsigned short*>(Yw));
+        {   // EQ_TB == NT: one symbol per thread
+            const float g0 = tid < nbs ? gx[b0 + tid - l.sym_lo] : 0.f;
+            const float g1 = (!REAL && tid < nbs) ? gx[l.sym_cnt + (b0 + tid - l.sym_lo)] : 0.f;
+            g2[tid] = f2{g0, g1};
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const f32x4* g4 = reinterpret_cast<const f32x4*>(g2 + wv * 64 + 32 * s + 8 * kq);   // (g0, g1) of two symbols per read
+#pragma unroll
+            for (int ib = 0; ib < NB16; ++ib) {
+                // ---- A operands of block ib: rho, sigma, -rho in three pieces each, two symbols per word (plain vector
+                //      instructions throughout: packed f32 arithmetic stalls beside the bf16 matrix instructions)
+                u32x4 rho[3], sig[3], nrho[3];
+#pragma unroll
+                for (int k2 = 0; k2 < 4; ++k2) {
+                    unsigned pr[2][3], ps[2][3];
+                    const f32x4 gg = g4[k2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int k = 2 * k2 + u;
+                        const f2 x = pa[ib][(32 * s + k) * S];
+                        const float g0 = gg[2 * u], g1 = gg[2 * u + 1];
+                        const float r = REAL ? g0 * x.x : fmaf(g1, x.y, g0 * x.x);
+                        bf_split3(r, &pr[u][0], &pr[u][1], &pr[u][2]);
+                        if (!REAL) {
+                            const float sg = fmaf(g1, x.x, -(g0 * x.y));
+                            bf_split3(sg, &ps[u][0], &ps[u][1], &ps[u][2]);
+                        }
+                    }
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        rho[p][k2] = bf_pack_hi(pr[0][p], pr[1][p]);
+                        if (!REAL) {
+                            sig[p][k2] = bf_pack_hi(ps[0][p], ps[1][p]);
+                            nrho[p][k2] = rho[p][k2] ^ 0x80008000u;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int jb = ib; jb < NB16; ++jb) {
+                    const int q = ib * NB16 - ib * (ib - 1) / 2 + (jb - ib);
+                    // piece dp of the B operand with the pieces tp <= 2 - dp of the A operand: the six products whose weight
+                    // is not below 2^-24 of the whole, the small pieces first
+#pragma unroll
+                    for (int dp = 2; dp >= 0; --dp) {
+                        // (one opaque address register per piece: the offset field of the reads reaches the plane of stream b)
+                        lword_p pw = pb[jb] + (REAL ? dp : 2 * dp) * nwd + 16 * s;
+                        asm volatile("" : "+v"(pw));
+                        u32x4 ya, yb;
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            ya[w] = pw[w];
+                            if (!REAL) yb[w] = pw[nwd + w];
+                        }
+#pragma unroll
+                        for (int tp = 2 - dp; tp >= 0; --tp) {
+                            Ar[q] = MFMA16BF(rho[tp], ya, Ar[q]);
+                            if (!REAL) {
+                                Ai[q] = MFMA16BF(sig[tp], ya, Ai[q]);
+                                Ar[q] = MFMA16BF(sig[tp], yb, Ar[q]);
+                                Ai[q] = MFMA16BF(nrho[tp], yb, Ai[q]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // fixed-order reduction of the four waves through LDS, then one record per block: [2 planes][LD][LD], lower blocks left zero
+    __syncthreads();
+    float* img = sm;  // [2][LD * LD]
+    for (int e = tid; e < 2 * LD * LD; e += NT) img[e] = 0.f;
+    __syncthreads();
+    for (int w = 0; w < 4; ++w) {
+        if (wv == w) {
+#pragma unroll
+            for (int ib = 0; ib < NB16; ++ib)
+#pragma unroll
+                for (int jb = ib; jb < NB16; ++jb) {
+                    const int q = ib * NB16 - ib * (ib - 1) / 2 + (jb - ib);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int e = (16 * ib + 4 * kq + g) * LD + 16 * jb + i16;
+                        img[e] += Ar[q][g];
+                        if (!REAL) img[LD * LD + e] += Ai[q][g];
+                    }
+                }
+        }
+        __syncthreads();
+    }
+    float* rec = ws + l.o_part_eqcx + (size_t)blockIdx.x * (2 * LD * LD);
+    for (int e = tid; e < 2 * LD * LD; e += NT) rec[e] = img[e];
+}
+
 // chain rule of the equaliser gradients (body: v2vae_chain_cx.h)
 __global__ __launch_bounds__(NT) void k_chain_equaliser_cx(Lay l, const float* __restrict__ ws, float* __restrict__ g_k1,
                                                            float* __restrict__ g_k2) {
@@ -200,6 +433,31 @@ int launch_eq_bwd_cx(const Lay& l, const float* y, const float* gx, float* ws, h
         else if (l.S == 2) V2VAE_LAUNCH_EQB16_S(NB, 2); \
         else V2VAE_LAUNCH_EQB16_S(NB, 0);            \
     } while (0)
+    if (l.eqbf) {
+#define V2VAE_LAUNCH_EQBF_R(NB, SS, RR)                                                                                          \
+    do {                                                                                                                         \
+        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k_eq_bwd_bf<NB, SS, RR>),                        \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)               \
+            return V2VAE_ELAUNCH;                                                                                                \
+        hipLaunchKernelGGL((k_eq_bwd_bf<NB, SS, RR>), dim3(l.nblk_eq), dim3(NT), lds, st, l, y, gx, ws);                          \
+    } while (0)
+#define V2VAE_LAUNCH_EQBF(NB)                                                \
+    do {                                                                     \
+        if (l.S == 1) { if (l.ns == 1) V2VAE_LAUNCH_EQBF_R(NB, 1, true); else V2VAE_LAUNCH_EQBF_R(NB, 1, false); } \
+        else { if (l.ns == 1) V2VAE_LAUNCH_EQBF_R(NB, 2, true); else V2VAE_LAUNCH_EQBF_R(NB, 2, false); }          \
+    } while (0)
+        switch (l.eqb16) {
+            case 1: V2VAE_LAUNCH_EQBF(1); break;
+            case 2: V2VAE_LAUNCH_EQBF(2); break;
+            case 3: V2VAE_LAUNCH_EQBF(3); break;
+            case 4: V2VAE_LAUNCH_EQBF(4); break;
+            case 5: V2VAE_LAUNCH_EQBF(5); break;
+            default: return V2VAE_ESIZE;
+        }
+#undef V2VAE_LAUNCH_EQBF
+#undef V2VAE_LAUNCH_EQBF_R
+        return V2VAE_OK;
+    }
     switch (l.eqb16) {
         case 1: V2VAE_LAUNCH_EQB16(1); break;
         case 2: V2VAE_LAUNCH_EQB16(2); break;

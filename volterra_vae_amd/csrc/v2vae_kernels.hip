@@ -27,7 +27,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     if (!p || !out) return V2VAE_EINVAL;
     Lay l{};
     l.ns = p->ns; l.S = p->sps;
-    if (p->flags & ~(V2VAE_FLAG_GENERIC | V2VAE_FLAG_EQ_MFMA_FWD | V2VAE_FLAG_ELBO_TILES | V2VAE_FLAG_REAL_MFMA) || p->reserved != 0) return V2VAE_EINVAL;
+    if (p->flags & ~(V2VAE_FLAG_GENERIC | V2VAE_FLAG_EQ_MFMA_FWD | V2VAE_FLAG_ELBO_TILES | V2VAE_FLAG_REAL_MFMA | V2VAE_FLAG_F32_MATRIX) || p->reserved != 0) return V2VAE_EINVAL;
     l.flags = p->flags;
     if (p->mode < 0 || p->mode > 3) return V2VAE_EINVAL;
     l.chan = p->mode >= 2 ? p->mode - 1 : 0;  // modes 2, 3: real path with a polynomial channel model
@@ -211,12 +211,20 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     if (l.cx_real && l.l2 >= 1 && l.l2 <= 79 && (l.l1 & 1) && l.l1 <= l.l2 && l.pad1 == l.l1 / 2)
         l.eqb16 = (l.l2 + 1 + 15) / 16;
     l.eqb16_rec = 2 * (16 * l.eqb16) * (16 * l.eqb16);
+    l.eqbf = (l.eqb16 && l.S <= 2 && !(l.flags & V2VAE_FLAG_F32_MATRIX)) ? 1 : 0;
     {
         // sample tile (interleaved pairs), per-symbol gradient combinations (5 per symbol), constant ones / zeros (64 S each); afterwards the record
-        const int64_t a = (((int64_t)2 * l.tile_len + 3) & ~(int64_t)3) + 5 * EQ_TB + 128 * l.S, b = l.eqb16_rec;
+        int64_t a = (((int64_t)2 * l.tile_len + 3) & ~(int64_t)3) + 5 * EQ_TB + 128 * l.S;
+        const int64_t b = l.eqb16_rec;
+        // bf16 instance: (g0, g1) per symbol instead of the five combinations, then the (copy, parity) regions of bf16 pairs and the constant region
+        if (l.eqbf) a = (((int64_t)2 * l.tile_len + 3) & ~(int64_t)3) + 2 * EQ_TB + 128 * l.S + ((int64_t)2 * l.S + 1) * ((l.ns == 1 ? 3 : 6) * EQBF_NWD + 8);
         l.lds_eqb16 = (int)((a > b ? a : b) * 4);
     }
-    if (l.eqb16) l.nblk_eq = l.eqb16 <= 3 ? (l.ntile_eq < 1024 ? l.ntile_eq : 1024) : (l.ntile_eq < 512 ? l.ntile_eq : 512);
+    if (l.eqb16) {
+        // (the bf16 instance with three lag blocks holds three workgroups per CU)
+        const int res = 256 * (l.eqb16 <= 2 ? 4 : l.eqb16 == 3 ? (l.eqbf ? 3 : 4) : 2);
+        l.nblk_eq = l.ntile_eq < res ? l.ntile_eq : res;
+    }
     else if (l.use_eqcxb && l.eqcxb_nbl >= 3) l.nblk_eq = l.ntile_eq < 256 ? l.ntile_eq : 256;
     if (!generic_eq_ok && !l.use_eqcxb) return V2VAE_ESIZE;
     l.rec_elbo = l.S * rec_elbo_phase(l);

@@ -19,6 +19,8 @@ namespace v2vae {
 constexpr int NT = 256;         // threads per workgroup (4 waves of 64)
 constexpr int MAX_C = 16;       // amplitude levels per stream
 constexpr int EQ_TB = 256;      // symbols per equaliser tile
+constexpr int EQBF_NWD = 176;   // k_eq_bwd_bf: words per plane of bf16 pairs: the elements of one parity of the longest tile
+                                // (256 S + 83 samples at 79 lags), in pairs, with slack for the last operand
 constexpr int LDS_BUDGET = 163000;  // one workgroup may use (almost) all 160 KiB of a CU
 constexpr int SCRATCH_F = 4096; // floats of LDS scratch for cross-chunk reductions
 constexpr int MAX_BLOCKS = 512; // persistent workgroups per kernel (2 per CU)
@@ -92,6 +94,7 @@ struct Lay {
     // backward of the complex equaliser on 16-lag blocks (k_eq_bwd_cx<NB16>): eqb16 = number of blocks (0: not used; l2 <= 79),
     // records [2 planes][16 eqb16][16 eqb16] at o_part_eqcx / o_tot_eqcx
     int eqb16, eqb16_rec, lds_eqb16;
+    int eqbf;                // 1: its instance on the bf16 matrix pipe in split arithmetic (k_eq_bwd_bf: one or two samples per symbol)
     int64_t o_part_eqcx, o_tot_eqcx;
     // blocked matrix-core equaliser path (complex, 31 < l2 <= 95): lag rows in blocks of 32
     int use_eqcxb, eqcxb_fwd, eqcxb_nbl, eqcxb_rec, lds_eqcxb_fwd, lds_eqcxb_bwd;
