@@ -489,10 +489,10 @@ constexpr int CX3_ADB = 16 * 32 + 4;        // 4-vectors of the anti-diagonal bu
 __host__ __device__ constexpr int cx3_wave_f(int S, bool BFX) {
     return 7 * cx3_ms(S, BFX) + 4 * cx3_ms(S, BFX) + 4 * CX3_ADB + (BFX ? 3 * cx3_ms(S, BFX) : 0);
 }
-// floats of one phase's constant operands: f32 images [steps][64] (H X and H w; H w alone with BFX), and with BFX the bf16
-// image of the H X table [3 pieces][2 chunks][64 lanes][8]
-__host__ __device__ constexpr int cx3_tab_f32(int NK, bool BFX) { return (BFX ? NK : 2 * NK) * 64; }
-constexpr int CX3_TAB_BF = 3 * 2 * 64 * 8 / 2;
+// floats of one phase's constant operands: f32 images [steps][64] of H X and H w, or with BFX the bf16 images of the two
+// tables, [2 tables][3 pieces][2 chunks][64 lanes][8] (two bytes each)
+__host__ __device__ constexpr int cx3_tab_f32(int NK, bool BFX) { return BFX ? 0 : 2 * NK * 64; }
+constexpr int CX3_TAB_BF = 2 * 3 * 2 * 64 * 8 / 2;
 
 __host__ __device__ constexpr int cx3_lds_floats(int S, int NK, bool BFX) {
     return S * cx3_tab_f32(NK, BFX) + S * 64 + (BFX ? S * CX3_TAB_BF : 0) + CX3_NW * cx3_wave_f(S, BFX);
@@ -515,11 +515,12 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
     constexpr int CX3_NT = NW * 64;
     static_assert(NK == 16 || NK == 13, "k-step counts with an operand schedule");
     constexpr int NA = cx3_tab_f32(NK, BFX) / 64;   // f32 A-operand steps per phase
-    constexpr int HW0 = BFX ? 0 : NK;          // first step of the H w operands
-    float* s_A = sm;                           // [S][NA][64]    A operands: steps 0..NK-1 H X (not with BFX), then NK steps of H w
+    constexpr int HW0 = NK;                    // first step of the H w operands
+    float* s_A = sm;                           // [S][NA][64]    A operands (not with BFX): steps 0..NK-1 H X, then NK steps of H w
     float* s_c = s_A + S * NA * 64;            // [S][4][16]     h1r, h1i, diag Hr, diag Hi
-    // BFX: the H X table in bf16 pieces, [S][3 pieces][2 chunks][64 lanes][8]: lane (row, half), element j of chunk c is the
-    // entry of k-slot (stream = half, tap = 8 c + j)
+    // BFX: the two tables in bf16 pieces, [S][2 tables][3 pieces][2 chunks][64 lanes][8]: lane (row, half), element j of chunk c
+    // is the entry of k-slot (stream = half, tap = 8 c + j) of H X, of k-slot (stream = c, tap = cx_kk(j, half)) of H w - the
+    // tap that accumulator slot j of that lane half holds, so the per-tap algebra's (alpha, beta) are the B operand as they are
     unsigned short* s_Ab = reinterpret_cast<unsigned short*>(s_c + S * 64);
     float* s_W = s_c + S * 64 + (BFX ? S * CX3_TAB_BF : 0);   // [NW][CX3_WAVE_F]
     __shared__ double dred[CX3_NT / 64];
@@ -541,7 +542,7 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
     // ---- constants of every phase into LDS (compile-time trip count: unrolled, so that the loads of all passes are in flight together)
 #pragma unroll
     for (int idx = tid; idx < S * NA * 64; idx += CX3_NT) {
-        const int ln = idx & 63, s = (idx >> 6) % NA + (BFX ? NK : 0), rr = idx / (NA * 64);
+        const int ln = idx & 63, s = (idx >> 6) % (BFX ? 1 : NA), rr = idx / ((BFX ? 1 : NA) * 64);
         const int jj = ln & 31, hh = ln >> 5, cjj = jj >> 4, yjj = jj & 15;
         const float* Hr = ws + l.o_cxH + (size_t)(rr * 2 + 0) * 256;
         const float* Hi = ws + l.o_cxH + (size_t)(rr * 2 + 1) * 256;
@@ -563,21 +564,24 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
     }
     if (BFX) {
 #pragma unroll
-        for (int idx = tid; idx < S * 2 * 64 * 8; idx += CX3_NT) {
-            const int j = idx & 7, ln = (idx >> 3) & 63, c = (idx >> 9) & 1, rr = idx >> 10;
-            const int jj = ln & 31, ck = ln >> 5, cjj = jj >> 4, yjj = jj & 15, xk = 8 * c + j;
+        for (int idx = tid; idx < S * 2 * 2 * 64 * 8; idx += CX3_NT) {
+            const int j = idx & 7, ln = (idx >> 3) & 63, c = (idx >> 9) & 1, tb = (idx >> 10) & 1, rr = idx >> 11;
+            const int jj = ln & 31, hh = ln >> 5, cjj = jj >> 4, yjj = jj & 15;
+            const int ck = tb ? c : hh, xk = tb ? cx_kk(j, hh) : 8 * c + j;
             const float* Hr = ws + l.o_cxH + (size_t)(rr * 2 + 0) * 256;
             const float* Hi = ws + l.o_cxH + (size_t)(rr * 2 + 1) * 256;
             float a = Hr[xk * 16 + yjj], b = Hi[xk * 16 + yjj];
-            // NK = 13: output row 13 (no such tap) computes the first-order term h1 . X of the window instead
-            if (NK == 13 && yjj == 13) { a = ws[l.o_cxh1 + (rr * 2 + 0) * 16 + xk]; b = ws[l.o_cxh1 + (rr * 2 + 1) * 16 + xk]; }
-            float v = ck == 0 ? (cjj == 0 ? a : b) : (cjj == 0 ? -b : a);
+            // NK = 13: output row 13 of H X (no such tap) computes the first-order term h1 . X of the window instead
+            if (!tb && NK == 13 && yjj == 13) { a = ws[l.o_cxh1 + (rr * 2 + 0) * 16 + xk]; b = ws[l.o_cxh1 + (rr * 2 + 1) * 16 + xk]; }
+            // H X: [[Hr, Hi], [-Hi, Hr]];  H w: 2 [[Hr, -Hi], [Hi, Hr]] (doubled: the operand the chain takes is w / 2)
+            float v = tb ? 2.f * (ck == 0 ? (cjj == 0 ? a : -b) : (cjj == 0 ? b : a))
+                         : (ck == 0 ? (cjj == 0 ? a : b) : (cjj == 0 ? -b : a));
             if (xk >= NK) v = 0.f;
             const unsigned b1 = __float_as_uint(v) & 0xFFFF0000u;
             const float r1 = v - __uint_as_float(b1);
             const unsigned b2 = __float_as_uint(r1) & 0xFFFF0000u;
             const float r2 = r1 - __uint_as_float(b2);
-            unsigned short* d = s_Ab + ((size_t)(rr * 3) * 2 + c) * 512 + ln * 8 + j;
+            unsigned short* d = s_Ab + ((size_t)((rr * 2 + tb) * 3) * 2 + c) * 512 + ln * 8 + j;
             d[0] = (unsigned short)(b1 >> 16);
             d[2 * 512] = (unsigned short)(b2 >> 16);
             d[4 * 512] = (unsigned short)(__float_as_uint(r2) >> 16);
@@ -591,7 +595,7 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
                  : q == 2 ? Hr[x * 16 + x] : Hi[x * 16 + x];
     }
     const float* Aop = s_A + (size_t)r * NA * 64 + lane;
-    const u32x4* Abf = reinterpret_cast<const u32x4*>(s_Ab) + (size_t)r * 6 * 64 + lane;   // [piece][chunk][64]
+    const u32x4* Abf = reinterpret_cast<const u32x4*>(s_Ab) + (size_t)r * 12 * 64 + lane;   // [table][piece][chunk][64]
     const float* cst = s_c + r * 64 + 4 * h;
     __syncthreads();
 
@@ -825,7 +829,31 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
             STAMP(2);
             // ---- H w: k-slot (s, h) carries the (stream, tap) of cx3_hw_slot
             f32x16 HW = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (NK == 16) {
+            if (BFX) {
+                // (alpha, beta) / 2 of the lane's eight taps in three bf16 pieces each (plain vector instructions: they run
+                // beside the matrix pipe), chunk 0 = alpha, chunk 1 = beta
+                u32x4 d[3][2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const f2 v = c ? be[p] : al[p];
+                        const unsigned a1 = __float_as_uint(v.x) & 0xFFFF0000u, b1 = __float_as_uint(v.y) & 0xFFFF0000u;
+                        const float ra = v.x - __uint_as_float(a1), rb = v.y - __uint_as_float(b1);
+                        const unsigned a2 = __float_as_uint(ra) & 0xFFFF0000u, b2 = __float_as_uint(rb) & 0xFFFF0000u;
+                        const float sa = ra - __uint_as_float(a2), sb = rb - __uint_as_float(b2);
+                        d[0][c][p] = __builtin_amdgcn_perm(b1, a1, 0x07060302u);
+                        d[1][c][p] = __builtin_amdgcn_perm(b2, a2, 0x07060302u);
+                        d[2][c][p] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
+                    }
+                constexpr int TP6[6] = {0, 1, 2, 0, 1, 0}, DP6[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+                        HW = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bfx8, Abf[((3 + TP6[k]) * 2 + c) * 64]),
+                                                                     __builtin_bit_cast(bfx8, d[DP6[k]][c]), HW, 0, 0, 0);
+            } else if (NK == 16) {
 #pragma unroll
                 for (int s = 0; s < (REAL ? 8 : 16); ++s)   // (REAL: beta is zero)
                     HW = MFMA32(Aop[(HW0 + s) * 64], s < 8 ? al[(s & 7) >> 1][s & 1] : be[(s & 7) >> 1][s & 1], HW);
