@@ -59,29 +59,32 @@ __global__ __launch_bounds__(NT) void k_prep_cxb(Lay l, const float* __restrict_
         if (t >= 0) v = q == 0 ? h1[t] : q == 1 ? h1[l.L + t] : cxb_H(l, h2, r, q - 2, x, x);
         ws[l.o_cxbc + idx] = v;
     }
-    // A-operand images [r][xb][jb][40 steps][64 lanes]; row index (output) jj = lane & 31 -> (stream cjj, tap yjj of block xb),
-    // contraction slots as in the single-block kernel, taps of block jb
-    const int64_t total = (int64_t)l.S * NB * NB * 40 * 64;
+    // Constant operand images [r][xb][jb][2 tables][3 pieces][2 chunks][64 lanes][4 words of two bf16]: the tables of the H X and
+    // H w products as three exact bf16 pieces (split arithmetic on the bf16 matrix pipe).  Lane (row jj = lane & 31 -> (stream
+    // cjj, tap 16 xb + (jj & 15)) of the output, half hh = lane >> 5); element j of chunk c is the entry of the k-slot
+    //   H X: (stream c, tap 16 jb + 8 hh + j)           [[Hr, Hi], [-Hi, Hr]]
+    //   H w: (stream c, tap 16 jb + cx_kk(j, hh))       [[Hr, -Hi], [Hi, Hr]]   (the tap accumulator slot j of that half holds)
+    const int64_t total = (int64_t)l.S * NB * NB * CXB_STEPS * 64;
     for (int64_t idx = tid; idx < total; idx += nth) {
-        const int ln = (int)(idx & 63), s = (int)((idx >> 6) % 40);
-        const int pair = (int)((idx / (40 * 64)) % (NB * NB)), r = (int)(idx / ((int64_t)40 * 64 * NB * NB));
+        const int f = (int)(idx % (CXB_STEPS * 64));
+        const int pair = (int)((idx / (CXB_STEPS * 64)) % (NB * NB)), r = (int)(idx / ((int64_t)CXB_STEPS * 64 * NB * NB));
         const int xb = pair / NB, jb = pair % NB;
+        const int w = f & 3, ln = (f >> 2) & 63, ck = (f >> 8) & 1, pc = (f >> 9) % 3, tb = f / 1536;
         const int jj = ln & 31, hh = ln >> 5, cjj = jj >> 4, yo = 16 * xb + (jj & 15);
-        float v;
-        if (s < 16) {          // [[Hr, Hi], [-Hi, Hr]], k = 2 s + h
-            const int k = 2 * s + hh, ck = k >> 4, xi = 16 * jb + (k & 15);
+        unsigned word = 0;
+        for (int u = 0; u < 2; ++u) {
+            const int j = 2 * w + u;
+            const int xi = 16 * jb + (tb ? cx_kk(j, hh) : 8 * hh + j);
             const float a = cxb_H(l, h2, r, 0, xi, yo), b = cxb_H(l, h2, r, 1, xi, yo);
-            v = ck == 0 ? (cjj == 0 ? a : b) : (cjj == 0 ? -b : a);
-        } else if (s < 24) {   // |H|^2, k = 2 (s - 16) + h
-            const int xi = 16 * jb + 2 * (s - 16) + hh;
-            const float a = cxb_H(l, h2, r, 0, yo, xi), b = cxb_H(l, h2, r, 1, yo, xi);
-            v = cjj == 0 ? a * a + b * b : 0.f;
-        } else {               // [[Hr, -Hi], [Hi, Hr]], k-slot <-> (stream (s - 24) >> 3, tap kk((s - 24) & 7, h))
-            const int s2 = s - 24, ck = s2 >> 3, xi = 16 * jb + cx_kk(s2 & 7, hh);
-            const float a = cxb_H(l, h2, r, 0, xi, yo), b = cxb_H(l, h2, r, 1, xi, yo);
-            v = ck == 0 ? (cjj == 0 ? a : -b) : (cjj == 0 ? b : a);
+            float t = tb ? (ck == 0 ? (cjj == 0 ? a : -b) : (cjj == 0 ? b : a)) : (ck == 0 ? (cjj == 0 ? a : b) : (cjj == 0 ? -b : a));
+            unsigned bits = 0;
+            for (int q = 0; q <= pc; ++q) {   // piece pc of t: truncate, subtract, repeat
+                bits = __float_as_uint(t) & 0xFFFF0000u;
+                t -= __uint_as_float(bits);
+            }
+            word |= (bits >> 16) << (16 * u);
         }
-        ws[l.o_cxbA + idx] = v;
+        ws[l.o_cxbA + idx] = __uint_as_float(word);
     }
     // extra-tap steps [r][xb][kind][64 lanes] behind the block-pair images: the two k-slots are the two streams of tap e = 16 NB;
     // kind 0 = [[Hr, Hi], [-Hi, Hr]] (pass A), kind 1 = [[Hr, -Hi], [Hi, Hr]] (pass B)
@@ -117,6 +120,8 @@ __global__ __launch_bounds__(cxb_nw(NB, XT) * 64) void k_elbo_cxb(Lay l, const f
     float* s_rec = s_P + S * NU * 4 * NSIG;    // [S][REC] after the last tile; before that [NW][32 windows][TVP]: per wave the four
                                                // per-(window, tap) terms of the vector gradients of one tap block, to be transposed
     float* s_xe = s_rec + RECA;                // XT: [S][2][LEB] row e of the symmetrised kernel (Re, Im)
+    // the means in three exact bf16 pieces each, [2 streams][3 pieces][MS] (two bytes each): B operands of the H X product
+    unsigned short* s_xb = reinterpret_cast<unsigned short*>(s_xe + (XT ? S * 2 * LEB : 0));
     __shared__ double dred[NW];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(cxb_nw(NB, XT) * 64) void k_elbo_cxb(Lay l, const f
             s_xe[idx] = ws[l.o_cxbH + ((size_t)rp * LEB + EX) * LEB + j];
         }
     const float* xe = s_xe + r * 2 * LEB;   // xe[j] = Re H(j, e), xe[LEB + j] = Im H(j, e)
-    const float* __restrict__ Abase0 = ws + l.o_cxbA + (size_t)r * NB * NB * 40 * 64;
+    const float* __restrict__ Abase0 = ws + l.o_cxbA + (size_t)r * NB * NB * CXB_STEPS * 64;
     const unsigned ulane = lane;
     const float* cst = s_c + r * 4 * LEB;
     __syncthreads();
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(cxb_nw(NB, XT) * 64) void k_elbo_cxb(Lay l, const f
     f2 col[NB], row[NB];   // (Re, Im) of this lane's share of column e / row e of dE/dH
 #pragma unroll
     for (int a = 0; a < NB; ++a) { col[a] = 0.f; row[a] = 0.f; }
-    const float* __restrict__ Xbase0 = ws + l.o_cxbA + (size_t)S * NB * NB * 40 * 64 + (size_t)r * NB * 2 * 64;
+    const float* __restrict__ Xbase0 = ws + l.o_cxbA + (size_t)S * NB * NB * CXB_STEPS * 64 + (size_t)r * NB * 2 * 64;
     double Eacc = 0.0;
 #ifdef V2VAE_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
@@ -224,6 +229,18 @@ __global__ __launch_bounds__(cxb_nw(NB, XT) * 64) void k_elbo_cxb(Lay l, const f
             if (ms < MS) {
                 dst[ms] = prea[u].x;
                 dst[MS + ms] = preb[u].x;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const float x = c ? preb[u].x : prea[u].x;
+                    const unsigned b1 = __float_as_uint(x) & 0xFFFF0000u;
+                    const float r1 = x - __uint_as_float(b1);
+                    const unsigned b2 = __float_as_uint(r1) & 0xFFFF0000u;
+                    const float r2 = r1 - __uint_as_float(b2);
+                    unsigned short* d = s_xb + c * 3 * MS + ms;
+                    d[0] = (unsigned short)(b1 >> 16);
+                    d[MS] = (unsigned short)(b2 >> 16);
+                    d[2 * MS] = (unsigned short)(__float_as_uint(r2) >> 16);
+                }
                 dst[2 * MS + ms] = prea[u].y + preb[u].y;
                 dst[3 * MS + ms] = prea[u].y - preb[u].y;
                 dst[4 * MS + ms] = prea[u].z;
@@ -277,9 +294,14 @@ __global__ __launch_bounds__(cxb_nw(NB, XT) * 64) void k_elbo_cxb(Lay l, const f
             f2 a0v = 0.f, a1v = 0.f, q0v = 0.f, q1v = 0.f, sd0v = 0.f, sd1v = 0.f, vsv = 0.f;
             // the A operands of block pair p + 1 are requested before the MFMA chain of pair p is issued; sched_barrier keeps
             // the compiler from hoisting more than that one pair of loads (register budget)
-            float abuf[2][16];   // two register sets, alternating by block pair: no copies
+            u32x4 abuf[2][6];    // two register sets, alternating by block pair: no copies; [piece][chunk] images of 16 bytes per lane
+            typedef const u32x4 __attribute__((address_space(1))) * gvec_p;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) abuf[0][s] = Abase[s * 64 + ulane];
+            for (int s = 0; s < 6; ++s) abuf[0][s] = ((gvec_p)Abase)[s * 64 + ulane];
+            // B operands: k-slot (chunk c, lane half h, element j) = (stream c, tap 8 h + j of block jb), i.e. eight consecutive bf16
+            // of stream c from staged symbol tsl + i + 16 jb + 8 h on: five aligned words, an odd window shifts by one piece
+            typedef const unsigned __attribute__((address_space(3))) * lword_p;
+            const unsigned sh = (i & 1) * 16;
             const float* Xbase_generic = Xbase0;
             asm volatile("" : "+s"(Xbase_generic));
             const gfloat_p Xbase = (gfloat_p)Xbase_generic;
@@ -301,15 +323,33 @@ __global__ __launch_bounds__(cxb_nw(NB, XT) * 64) void k_elbo_cxb(Lay l, const f
                     const int pr = xb * NB + jb;
                     __builtin_amdgcn_sched_barrier(0);
                     if (pr + 1 < NB * NB) {
-                        const gfloat_p A = Abase + (size_t)(pr + 1) * 40 * 64;
+                        const gvec_p A = (gvec_p)(Abase + (size_t)(pr + 1) * CXB_STEPS * 64);
 #pragma unroll
-                        for (int s = 0; s < 16; ++s) abuf[(pr + 1) & 1][s] = A[s * 64 + ulane];
+                        for (int s = 0; s < 6; ++s) abuf[(pr + 1) & 1][s] = A[s * 64 + ulane];
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    {
+                        lword_p xw = (lword_p)(reinterpret_cast<const unsigned*>(s_xb) + ((tsl + i + 16 * jb + 8 * h) >> 1));
+                        asm volatile("" : "+v"(xw));
+                        u32x4 d[3][2];
 #pragma unroll
-                    for (int s = 0; s < 16; ++s) {
-                        const int k = 2 * s + h;
-                        U = MFMA32(abuf[pr & 1][s], s_mu[(k >> 4) * MS + tsl + i + 16 * jb + (k & 15)], U);
+                        for (int c = 0; c < 2; ++c)
+#pragma unroll
+                            for (int pc = 0; pc < 3; ++pc) {
+                                unsigned w[5];
+#pragma unroll
+                                for (int q = 0; q < 5; ++q) w[q] = xw[(c * 3 + pc) * (MS / 2) + q];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) d[pc][c][q] = __builtin_amdgcn_alignbit(w[q + 1], w[q], sh);
+                            }
+                        // table piece x operand piece, smallest products first: (1,3) (2,2) (3,1) (1,2) (2,1) (1,1)
+                        constexpr int TP6[6] = {0, 1, 2, 0, 1, 0}, DP6[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+                        for (int k = 0; k < 6; ++k)
+#pragma unroll
+                            for (int c = 0; c < 2; ++c)
+                                U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bfx8, abuf[pr & 1][TP6[k] * 2 + c]),
+                                                                            __builtin_bit_cast(bfx8, d[DP6[k]][c]), U, 0, 0, 0);
                     }
                     // (no (H.H) s product: the term of E that holds it and its variance gradient come from k_g2_cx)
                 }
@@ -426,9 +466,33 @@ __global__ __launch_bounds__(cxb_nw(NB, XT) * 64) void k_elbo_cxb(Lay l, const f
             }
 
             // ---- pass B: per output block H w, the anti-diagonal sums of the moment gradients, dE/dH
-            float hbuf[2][16];
+            u32x4 hbuf[2][6];
 #pragma unroll
-            for (int s = 0; s < 16; ++s) hbuf[0][s] = Abase[(24 + s) * 64 + ulane];
+            for (int s = 0; s < 6; ++s) hbuf[0][s] = ((gvec_p)Abase)[(6 + s) * 64 + ulane];
+            // B operands of H w: (alpha, beta) of the lane's eight taps of block jb in three bf16 pieces each (plain vector
+            // instructions: they run beside the matrix pipe), chunk 0 = alpha, chunk 1 = beta.  Up to two blocks they are formed
+            // once per slab; with three the registers do not reach and every output block forms them again.
+            auto split_w = [&](int jb, u32x4 (&d)[3][2]) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const f2 v = c ? be[jb][p] : al[jb][p];
+                        const unsigned a1 = __float_as_uint(v.x) & 0xFFFF0000u, b1 = __float_as_uint(v.y) & 0xFFFF0000u;
+                        const float ra = v.x - __uint_as_float(a1), rb = v.y - __uint_as_float(b1);
+                        const unsigned a2 = __float_as_uint(ra) & 0xFFFF0000u, b2 = __float_as_uint(rb) & 0xFFFF0000u;
+                        const float sa = ra - __uint_as_float(a2), sb = rb - __uint_as_float(b2);
+                        d[0][c][p] = __builtin_amdgcn_perm(b1, a1, 0x07060302u);
+                        d[1][c][p] = __builtin_amdgcn_perm(b2, a2, 0x07060302u);
+                        d[2][c][p] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
+                    }
+            };
+            constexpr bool HOLDW = NB <= 2;
+            u32x4 wd[HOLDW ? NB : 1][3][2];
+            if (HOLDW) {
+#pragma unroll
+                for (int jb = 0; jb < NB; ++jb) split_w(jb, wd[jb]);
+            }
 #pragma unroll
             for (int xb = 0; xb < NB; ++xb) {
                 f32x16 HW;
@@ -439,14 +503,22 @@ __global__ __launch_bounds__(cxb_nw(NB, XT) * 64) void k_elbo_cxb(Lay l, const f
                     const int pr = xb * NB + jb;
                     __builtin_amdgcn_sched_barrier(0);
                     if (pr + 1 < NB * NB) {
-                        const gfloat_p A = Abase + ((size_t)(pr + 1) * 40 + 24) * 64;
+                        const gvec_p A = (gvec_p)(Abase + (size_t)(pr + 1) * CXB_STEPS * 64);
 #pragma unroll
-                        for (int s = 0; s < 16; ++s) hbuf[(pr + 1) & 1][s] = A[s * 64 + ulane];
+                        for (int s = 0; s < 6; ++s) hbuf[(pr + 1) & 1][s] = A[(6 + s) * 64 + ulane];
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    {
+                        if (!HOLDW) split_w(jb, wd[0]);
+                        const u32x4 (&d)[3][2] = wd[HOLDW ? jb : 0];
+                        constexpr int TP6[6] = {0, 1, 2, 0, 1, 0}, DP6[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
-                    for (int s = 0; s < 16; ++s)
-                        HW = MFMA32(hbuf[pr & 1][s], s < 8 ? al[jb][(s & 7) >> 1][s & 1] : be[jb][(s & 7) >> 1][s & 1], HW);
+                        for (int k = 0; k < 6; ++k)
+#pragma unroll
+                            for (int c = 0; c < 2; ++c)
+                                HW = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bfx8, hbuf[pr & 1][TP6[k] * 2 + c]),
+                                                                             __builtin_bit_cast(bfx8, d[DP6[k]][c]), HW, 0, 0, 0);
+                    }
                 }
                 if (XT) HW = MFMA32(xbufB[xb], h == 0 ? al_e : be_e, HW);
                 BSTAMP(3);

@@ -178,7 +178,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
             const int ms = CXB_TWB + l.cxb_leb + 16, nsig = 32 + l.cxb_leb;
             l.lds_cxb = ((7 * ms + 2 * l.S * CXB_TWB) + l.S * 4 * l.cxb_leb + CXB_NW * 32 * (l.cxb_xt ? CXB_TPX : CX_TP) +
                          l.S * (CXB_TWB / 32) * 4 * nsig + (l.S * l.cxb_rec > CXB_NW * 32 * 81 ? l.S * l.cxb_rec : CXB_NW * 32 * 81) +
-                         (l.cxb_xt ? l.S * 2 * l.cxb_leb : 0)) * 4;   // records / per-wave [32][81] transposing buffers share memory
+                         (l.cxb_xt ? l.S * 2 * l.cxb_leb : 0) + 3 * ms) * 4;   // records / per-wave [32][81] transposing buffers share memory; bf16 pieces of the means
         }
         l.nblk_E = l.use_cx ? l.nblk_cx + G2_NE : (l.use_cxb ? l.nblk_cxb + G2_NE : l.nblk_elbo);   // + 1: the lagged-product term of E (k_g2_cx)
         if (!l.use_cx && !l.use_cxb && !generic_elbo_ok) return V2VAE_ESIZE;
@@ -264,7 +264,7 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     l.o_g2c = take((l.use_cx || l.use_cxb) ? G2C_FLOATS : 0);
     l.o_gT = take((l.use_cx || l.use_cxb) ? l.sym_cnt : 0);
     l.o_psv = take((l.use_cx || l.use_cxb) ? (int64_t)l.S * l.LE * l.LE : 0);
-    l.o_cxbA = take(l.use_cxb ? (int64_t)l.S * l.cxb_nb * l.cxb_nb * 40 * 64 : 0);
+    l.o_cxbA = take(l.use_cxb ? (int64_t)l.S * l.cxb_nb * l.cxb_nb * CXB_STEPS * 64 : 0);
     l.o_cxbH = take(l.use_cxb ? (int64_t)l.S * 2 * l.cxb_leb * l.cxb_leb : 0);
     l.o_cxbc = take(l.use_cxb ? (int64_t)l.S * 4 * l.cxb_leb : 0);
     l.o_part_cxb = take(l.use_cxb ? (int64_t)l.nblk_cxb * l.S * l.cxb_rec : 0);
