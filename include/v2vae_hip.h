@@ -53,9 +53,10 @@ extern "C" {
                                     per tile) instead of the run kernel (every wave on its own run of windows); 17 or 33 active
                                     taps: whole blocks of 16 taps (2 or 3) instead of 1 or 2 blocks plus one tap on the side */
 
-#define V2VAE_FLAG_F32_MATRIX 16 /* one or two samples per symbol, l2 <= 79: the equaliser backward (and, complex model with <= 16
-                                    active taps per phase, the H X product of the run ELBO kernel) on f32 matrix instructions
-                                    instead of bf16 ones in three-piece split arithmetic */
+#define V2VAE_FLAG_F32_MATRIX 16 /* complex model, one or two samples per symbol: the kernels that by default run on bf16 matrix
+                                    instructions in three-piece split arithmetic - equaliser backward (l2 <= 95), equaliser forward
+                                    from 33 lags on, the H X and H w products of the run ELBO kernel (<= 16 active taps per phase) -
+                                    on f32 matrix instructions / the vector pipe instead (backward then l2 <= 79 on 16-lag blocks) */
 
 typedef struct v2vae_problem {
     int32_t ns;      /* 1 or 2 */

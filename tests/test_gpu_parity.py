@@ -377,10 +377,10 @@ def test_run_and_block_tile_elbo_kernels_agree(L, S, B):
 @pytest.mark.parametrize("L,S,l2,B", [(25, 2, 25, 5000), (25, 2, 25, 333), (9, 1, 15, 2049), (25, 2, 47, 1500), (9, 2, 65, 1300),
                                       (13, 1, 79, 900), (9, 2, 31, 257)])
 def test_split_bf16_and_f32_matrix_routes_agree(L, S, l2, B):
-    """Complex model: the equaliser backward (and, up to 16 active taps per phase, the H X product of the run ELBO kernel) on bf16
-    matrix instructions in three-piece split arithmetic - the default - against the same sums on f32 matrix instructions
-    (V2VAE_FLAG_F32_MATRIX): different programs, both exact to float rounding, at 1 ... 5 blocks of 16 lags, one and two samples
-    per symbol, tiles that end inside a block of 32 symbols."""
+    """Complex model: the equaliser forward and backward (and, up to 16 active taps per phase, the H X and H w products of the run
+    ELBO kernel) on bf16 matrix instructions in three-piece split arithmetic - the default - against the same sums on the vector
+    pipe / on f32 matrix instructions (V2VAE_FLAG_F32_MATRIX): different programs, both exact to float rounding, at 1 ... 5
+    blocks of 16 lags, one and two samples per symbol, tiles that end inside a block of 32 symbols."""
     from volterra_vae_amd import _lib
     from volterra_vae_amd.ops import Plan
     l1 = l2 if l2 <= 25 else 25
@@ -391,11 +391,15 @@ def test_split_bf16_and_f32_matrix_routes_agree(L, S, l2, B):
     for flags in (0, _lib.FLAG_F32_MATRIX):
         plan = Plan(ns=2, sps=S, l1=l1, pad1=l1 // 2, l2=l2, L=L, C_levels=M, n_glob=B * S, device="cuda", flags=flags)
         o = run_step(plan, dev(y), dev(h1), dev(h2), dev(k1), dev(k2), dev(levels), dev(prior), dev(scaling), dev(np.array([0.08])))
-        outs.append(dict(E=float(o["E"]), loss=float(o["loss"]), gx=o["gx"].clone(), **{k: v.clone() for k, v in o["g"].items()}))
+        outs.append(dict(E=float(o["E"]), loss=float(o["loss"]), gx=o["gx"].clone(), xhat=o["xhat"].clone(),
+                         **{k: v.clone() for k, v in o["g"].items()}))
     a, b = outs
     assert abs(a["E"] - b["E"]) < 1e-6 * abs(b["E"]) and abs(a["loss"] - b["loss"]) < 1e-6 * abs(b["loss"])
+    assert rel(a["xhat"], b["xhat"].cpu().numpy()) < 3e-7
+    # (the two forwards differ by float rounding of xhat, ~1e-7, which the soft demapper amplifies by 2 |xhat - level| /
+    # (noise variance * scaling) ~ 20 on its way into dloss/dxhat and the equaliser gradients)
     for k in ("gx", "h1", "h2", "k1", "k2", "sc"):
-        assert rel(a[k], b[k].cpu().numpy()) < 2e-6, k
+        assert rel(a[k], b[k].cpu().numpy()) < (TOL if k in ("gx", "k1", "k2", "sc") else 2e-6), k
 
 
 @pytest.mark.parametrize("ns,M,B", [(1, 4, 4096), (1, 4, 4099), (2, 4, 6000), (2, 8, 1001), (1, 2, 777), (2, 16, 2048), (1, 3, 5000)])

@@ -452,6 +452,7 @@ int launch_eq_bwd_cx(const Lay& l, const float* y, const float* gx, float* ws, h
             case 3: V2VAE_LAUNCH_EQBF(3); break;
             case 4: V2VAE_LAUNCH_EQBF(4); break;
             case 5: V2VAE_LAUNCH_EQBF(5); break;
+            case 6: V2VAE_LAUNCH_EQBF(6); break;
             default: return V2VAE_ESIZE;
         }
 #undef V2VAE_LAUNCH_EQBF

@@ -205,13 +205,15 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     if (l.use_eqcxb && l.lds_eqcxb_fwd > LDS_BUDGET) l.use_eqcxb = 0;
     // persistent backward kernels: exactly the workgroups that are resident at once (register use: 4 per CU for the
     // single-block kernel, 2 with two lag blocks, 1 with three), so that no partly filled second round trails the first
-    l.eqb16 = (l.use_eqcx || (l.use_eqcxb && l.l2 <= 79)) ? (l.l2 + 1 + 15) / 16 : 0;
+    // (the instance on the bf16 matrix pipe reaches 95 lags - six blocks -, the f32 one 79)
+    const bool eqbf_ok = l.S <= 2 && !(l.flags & V2VAE_FLAG_F32_MATRIX);
+    l.eqb16 = (l.use_eqcx || (l.use_eqcxb && l.l2 <= (eqbf_ok ? 95 : 79))) ? (l.l2 + 1 + 15) / 16 : 0;
     // the real model's equaliser BACKWARD runs the same kernel on a zero quadrature stream wherever its ELBO does (large batches;
     // any batch on request); the forward keeps the generic kernel, whose sums in double carry the remainder the demapper needs
     if (l.cx_real && l.l2 >= 1 && l.l2 <= 79 && (l.l1 & 1) && l.l1 <= l.l2 && l.pad1 == l.l1 / 2)
         l.eqb16 = (l.l2 + 1 + 15) / 16;
     l.eqb16_rec = 2 * (16 * l.eqb16) * (16 * l.eqb16);
-    l.eqbf = (l.eqb16 && l.S <= 2 && !(l.flags & V2VAE_FLAG_F32_MATRIX)) ? 1 : 0;
+    l.eqbf = (l.eqb16 && eqbf_ok) ? 1 : 0;
     {
         // sample tile (interleaved pairs), per-symbol gradient combinations (5 per symbol), constant ones / zeros (64 S each); afterwards the record
         int64_t a = (((int64_t)2 * l.tile_len + 3) & ~(int64_t)3) + 5 * EQ_TB + 128 * l.S;
@@ -279,6 +281,12 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     l.eqsymr = (l.cx_real && l.eqb16 && l.l2 <= 65) ? 1 : 0;
     if (l.eqsymr) l.eqsym_t = l.l2 <= 9 ? 9 : l.l2 <= 17 ? 17 : l.l2 <= 25 ? 25 : l.l2 <= 31 ? 31 : l.l2 <= 47 ? 47 : 65;
     l.o_eqsym = take(l.eqsym_t ? l.eqsym_t * (l.eqsym_t + 1) + 2 * l.eqsym_t + 16 : 0);
+    // (from three blocks of 16 lags on: up to 31 lags the symmetric form on the vector pipe is ahead, 0.130 against 0.150 ms per
+    // 2^22 symbols at 25 lags - there the closing stage, which the two share, is as long as the row sums)
+    l.eqfbf_nbk = (l.l2 + 15) / 16;
+    l.eqfbf = (l.mode == 1 && l.eqsym_t && !l.eqsymr && l.S <= 2 && l.eqfbf_nbk >= 3 &&
+               !(l.flags & (V2VAE_FLAG_F32_MATRIX | V2VAE_FLAG_EQ_MFMA_FWD))) ? 1 : 0;
+    l.o_eqfbf = take(l.eqfbf ? (int64_t)(l.eqfbf_nbk * (l.eqfbf_nbk + 1) / 2) * 1536 + 32 * l.eqfbf_nbk : 0);
     l.o_part_eqcxb = take((l.use_eqcxb && !l.eqb16) ? (int64_t)l.nblk_eq * l.eqcxb_rec : 0);
     l.o_tot_eqcxb = take((l.use_eqcxb && !l.eqb16) ? l.eqcxb_rec : 0);
     {
@@ -1901,6 +1909,10 @@ int v2vae_eq_fwd(const v2vae_problem* p, const float* y, void* ws, float* xhat, 
     int rc = make_layout(p, &l);
     if (rc) return rc;
     if (!y || !ws || !xhat) return V2VAE_EINVAL;
+    if (l.eqfbf) {
+        rc = launch_eq_fwd_bf(l, y, (const float*)ws, xhat, (hipStream_t)stream);
+        return rc ? rc : launch_status();
+    }
     if (l.eqcxb_fwd) {
         rc = launch_eq_fwd_cxb(l, y, (const float*)ws, xhat, (hipStream_t)stream);
         return rc ? rc : launch_status();

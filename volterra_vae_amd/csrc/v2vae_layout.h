@@ -19,8 +19,8 @@ namespace v2vae {
 constexpr int NT = 256;         // threads per workgroup (4 waves of 64)
 constexpr int MAX_C = 16;       // amplitude levels per stream
 constexpr int EQ_TB = 256;      // symbols per equaliser tile
-constexpr int EQBF_NWD = 176;   // k_eq_bwd_bf: words per plane of bf16 pairs: the elements of one parity of the longest tile
-                                // (256 S + 83 samples at 79 lags), in pairs, with slack for the last operand
+constexpr int EQBF_NWD = 192;   // k_eq_bwd_bf: words per plane of bf16 pairs: the elements of one parity of the longest tile
+                                // (256 S + 99 samples at 95 lags), in pairs, with slack for the last operand
 constexpr int LDS_BUDGET = 163000;  // one workgroup may use (almost) all 160 KiB of a CU
 constexpr int SCRATCH_F = 4096; // floats of LDS scratch for cross-chunk reductions
 constexpr int MAX_BLOCKS = 512; // persistent workgroups per kernel (2 per CU)
@@ -106,6 +106,11 @@ struct Lay {
     int eqsym_t;             // compile-time lag count of the kernel instance that serves l2 (0: not used)
     int eqsymr;              // 1: the real model's forward in symmetric form with sums in double (k_eq_fwd_symr); the table then holds doubles
     int64_t o_eqsym;
+    // forward of the complex equaliser on the bf16 matrix pipe in split arithmetic (k_eq_fwd_bf: one or two samples per symbol,
+    // up to 95 lags): eqfbf_nbk blocks of 16 lags; at o_eqfbf the table images [pairs (R, g >= R)][2 streams][3 pieces][64 lanes]
+    // [8 bf16], then the first-order weights on lag indices [16 eqfbf_nbk][2]
+    int eqfbf, eqfbf_nbk;
+    int64_t o_eqfbf;
     int64_t o_sumstage;      // 3 x [SUM_CHUNKS][largest record] staging of the two-stage record sums (one per record set)
     int64_t sumstage_stride; // floats between the three staging areas
     // record sizes of the per-workgroup partial sums (floats)
@@ -125,6 +130,7 @@ V2VAE_HD inline int rec_elbo_phase(const Lay& l) { return l.ns * l.LTp * l.LTp +
 
 int make_layout(const v2vae_problem* p, Lay* out);
 int launch_eq_fwd_cxb(const Lay& l, const float* y, const float* ws, float* xhat, hipStream_t st);
+int launch_eq_fwd_bf(const Lay& l, const float* y, const float* ws, float* xhat, hipStream_t st);   // v2vae_eq_fwd_bf.hip
 int launch_prep_eqsymr(const Lay& l, const float* k1, const float* k2, float* ws, hipStream_t st);
 int launch_eq_fwd_symr(const Lay& l, const float* y, float* ws, float* xhat, hipStream_t st);
 int launch_eq_bwd_cxb(const Lay& l, const float* y, const float* gx, float* ws, hipStream_t st);

@@ -38,6 +38,42 @@ __device__ __forceinline__ void d_prep_eqcxb(const Lay& l, const float* __restri
         const int jj = p1 + p2 - x;  // first-order tap that multiplies lag x
         ws[l.o_eqcxbA + n + idx] = (x < l2 && jj >= 0 && jj < l1) ? (plane == 0 ? k1r[jj] : k1i[jj]) : 0.f;
     }
+    if (l.eqfbf) {
+        // table images of the forward on the bf16 matrix pipe (k_eq_fwd_bf): [pairs (R, g >= R)][stream c][piece][64 lanes][4 words
+        // of two bf16].  Lane (jj, hh): matrix row jj = (Re | Im of u, lag a = 16 R + (jj & 15)); element j of the lane is the
+        // k-slot of lag b = 16 g + 8 hh + 7 - j of stream c.  Entry: [[K'r, -K'i], [K'i, K'r]] with K'_ab = K_ab (a = b),
+        // 2 K_ab (a < b), 0 (a > b, or a lag from l2 on), K = k2 + k2^T; each float as three exact bf16 pieces (by truncation).
+        const int NBK = l.eqfbf_nbk, NPW = NBK * (NBK + 1) / 2 * 1536;
+        for (int idx = bid * NT + threadIdx.x; idx < NPW; idx += nb * NT) {
+            const int w = idx & 3, ln = (idx >> 2) & 63, pc = (idx >> 8) % 3, c = (idx / 768) & 1;
+            int pi = idx / 1536, R = 0;
+            while (pi >= NBK - R) { pi -= NBK - R; ++R; }
+            const int g = R + pi;
+            const int jj = ln & 31, hh = ln >> 5, cjj = jj >> 4, a = 16 * R + (jj & 15);
+            unsigned word = 0;
+            for (int u = 0; u < 2; ++u) {
+                const int b = 16 * g + 8 * hh + 7 - (2 * w + u);
+                float t = 0.f;
+                if (a < l2 && b < l2 && b >= a) {
+                    const float sc = a == b ? 1.f : 2.f;
+                    const float kr = sc * (k2r[a * l2 + b] + k2r[b * l2 + a]), ki = sc * (k2i[a * l2 + b] + k2i[b * l2 + a]);
+                    t = c == 0 ? (cjj == 0 ? kr : ki) : (cjj == 0 ? -ki : kr);
+                }
+                unsigned bits = 0;
+                for (int q = 0; q <= pc; ++q) {   // piece pc of t: truncate, subtract, repeat
+                    bits = __float_as_uint(t) & 0xFFFF0000u;
+                    t -= __uint_as_float(bits);
+                }
+                word |= (bits >> 16) << (16 * u);
+            }
+            ws[l.o_eqfbf + idx] = __uint_as_float(word);
+        }
+        for (int idx = bid * NT + threadIdx.x; idx < 32 * NBK; idx += nb * NT) {
+            const int a = idx >> 1, plane = idx & 1;
+            const int jj = p1 + p2 - a;  // first-order tap that multiplies lag a
+            ws[l.o_eqfbf + NPW + idx] = (a < l2 && jj >= 0 && jj < l1) ? (plane == 0 ? k1r[jj] : k1i[jj]) : 0.f;
+        }
+    }
     if (l.eqsym_t) {   // table of the symmetric-form forward kernel (k_eq_fwd_sym): one stream of (Re, Im) entries, row after row,
                        // row a = [K'_aa, K'_a,a+1, ..., K'_a,T-1, first-order weight of lag a]; eight zero entries pad the end
         const int T = l.eqsym_t, ne = T * (T + 1) / 2 + T;
