@@ -39,9 +39,9 @@ def algorithmic_flops_per_symbol(L, S, l1, l2, cplx):
         # complex, up to 95 lags (k_eq_fwd_sym): symmetric form, l2 (l2 + 1) / 2 + l2 complex multiply-adds (first-order kernel
         # folded in); beyond that the full lag matrix is evaluated
         "eq_fwd": 8 * (l2 * (l2 + 1) // 2 + l2) if (cplx and l2 <= 95) else c * (2 * l1 + 2 * l2 * l2 + 2 * l2),
-        # the gradient planes are symmetric in the lag pair: the same count (k_eq_bwd_cx, up to 79 lags, accumulates the upper-
+        # the gradient planes are symmetric in the lag pair: the same count (k_eq_bwd_bf, up to 95 lags, accumulates the upper-
         # triangular 16x16 blocks only)
-        "eq_bwd": 8 * (l2 * (l2 + 1) // 2 + l2) if (cplx and l2 <= 79) else c * (2 * l1 + 2 * l2 * l2),
+        "eq_bwd": 8 * (l2 * (l2 + 1) // 2 + l2) if (cplx and l2 <= 95) else c * (2 * l1 + 2 * l2 * l2),
         "elbo_fused": (24 if cplx else 12) * L * L / S,
     }
 
@@ -332,7 +332,9 @@ def main():
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic, "pipe_bound_frac": pipe,
                          "algorithmic_flops_per_symbol": fl[dom], "kernel_ms": kernel_ms[dom],
-                         "whole_step_frac": step_flops / world / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_TFLOPS},
+                         "whole_step_frac": step_flops / world / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+                         "arithmetic": "float results; the table products of the matrix-core kernels run on bf16 matrix instructions in "
+                                       "three-piece split arithmetic (six piece products, float accumulation), priced against the f32 peak"},
             "kernel_ms": kernel_ms, "final_loss": final_loss,
         }
         if world == 1 and not args.no_cpu_baseline:
