@@ -28,7 +28,8 @@ def default_flags() -> int:
     """Kernel A/B switches for measurements and tooling, taken from the environment when a problem is set up
     (V2VAE_FORCE_GENERIC: generic FMA kernels everywhere; V2VAE_EQ_MFMA_FWD: matrix-core forward equaliser; V2VAE_ELBO_TILES:
     block-tile instead of run matrix-core ELBO kernel; V2VAE_REAL_MFMA: the real model on the matrix-core ELBO kernel at every batch
-    size, not only from 2^12 symbols on).  The
+    size, not only from 2^12 symbols on; V2VAE_F32_MATRIX: the f32 matrix / vector-pipe routes instead of the bf16 matrix instructions
+    in split arithmetic).  The
     library itself never reads the environment: the choice travels in `Problem.flags`."""
     return (FLAG_GENERIC if os.environ.get("V2VAE_FORCE_GENERIC") else 0) | \
         (FLAG_EQ_MFMA_FWD if os.environ.get("V2VAE_EQ_MFMA_FWD") else 0) | \
