@@ -21,6 +21,7 @@
 // left), so every per-symbol gradient is completed inside the block and gathered without atomics.
 #include <hip/hip_runtime.h>
 
+#include "v2vae_bf16_split.h"
 #include "v2vae_cx_common.h"
 #include "v2vae_chain_cx.h"
 #include "v2vae_layout.h"
@@ -577,14 +578,12 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
             float v = tb ? 2.f * (ck == 0 ? (cjj == 0 ? a : -b) : (cjj == 0 ? b : a))
                          : (ck == 0 ? (cjj == 0 ? a : b) : (cjj == 0 ? -b : a));
             if (xk >= NK) v = 0.f;
-            const unsigned b1 = __float_as_uint(v) & 0xFFFF0000u;
-            const float r1 = v - __uint_as_float(b1);
-            const unsigned b2 = __float_as_uint(r1) & 0xFFFF0000u;
-            const float r2 = r1 - __uint_as_float(b2);
+            unsigned b1, b2, b3;
+            bf16_split3_rne(v, &b1, &b2, &b3);   // (split once per workgroup: pieces rounded to nearest)
             unsigned short* d = s_Ab + ((size_t)((rr * 2 + tb) * 3) * 2 + c) * 512 + ln * 8 + j;
             d[0] = (unsigned short)(b1 >> 16);
             d[2 * 512] = (unsigned short)(b2 >> 16);
-            d[4 * 512] = (unsigned short)(__float_as_uint(r2) >> 16);
+            d[4 * 512] = (unsigned short)(b3 >> 16);
         }
     }
     for (int idx = tid; idx < S * 64; idx += CX3_NT) {
@@ -649,15 +648,13 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
         float* d = stg + e0 + i;
         if (i >= jmin) {
             d[h * MS] = pm[0];                                  // mean_a | mean_b
-            if (BFX) {   // and its three bf16 pieces (exact: 8 + 8 + 8 significand bits by truncation)
-                const unsigned b1 = __float_as_uint(pm[0]) & 0xFFFF0000u;
-                const float r1 = pm[0] - __uint_as_float(b1);
-                const unsigned b2 = __float_as_uint(r1) & 0xFFFF0000u;
-                const float r2 = r1 - __uint_as_float(b2);
+            if (BFX) {   // and its three bf16 pieces (exact sum, each rounded to nearest: split once per symbol)
+                unsigned b1, b2, b3;
+                bf16_split3_rne(pm[0], &b1, &b2, &b3);
                 unsigned short* x = Xb + h * 3 * MS + e0 + i;
                 x[0] = (unsigned short)(b1 >> 16);
                 x[MS] = (unsigned short)(b2 >> 16);
-                x[2 * MS] = (unsigned short)(__float_as_uint(r2) >> 16);
+                x[2 * MS] = (unsigned short)(b3 >> 16);
             }
             d[(2 + h) * MS] = h ? ov - pm[1] : pm[1] + ov;      // v_a + v_b | v_a - v_b
             d[(4 + h) * MS] = pm[2];                            // 3rd central moments

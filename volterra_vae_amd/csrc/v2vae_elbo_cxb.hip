@@ -23,6 +23,7 @@
 // 16x16 MFMAs read.  Tables and records keep the stride 16 (NB + 1).
 #include <hip/hip_runtime.h>
 
+#include "v2vae_bf16_split.h"
 #include "v2vae_cx_common.h"
 #include "v2vae_layout.h"
 
@@ -77,12 +78,7 @@ __global__ __launch_bounds__(NT) void k_prep_cxb(Lay l, const float* __restrict_
             const int xi = 16 * jb + (tb ? cx_kk(j, hh) : 8 * hh + j);
             const float a = cxb_H(l, h2, r, 0, xi, yo), b = cxb_H(l, h2, r, 1, xi, yo);
             float t = tb ? (ck == 0 ? (cjj == 0 ? a : -b) : (cjj == 0 ? b : a)) : (ck == 0 ? (cjj == 0 ? a : b) : (cjj == 0 ? -b : a));
-            unsigned bits = 0;
-            for (int q = 0; q <= pc; ++q) {   // piece pc of t: truncate, subtract, repeat
-                bits = __float_as_uint(t) & 0xFFFF0000u;
-                t -= __uint_as_float(bits);
-            }
-            word |= (bits >> 16) << (16 * u);
+            word |= bf16_piece_rne(t, pc) << (16 * u);   // (split once per step: pieces rounded to nearest)
         }
         ws[l.o_cxbA + idx] = __uint_as_float(word);
     }
@@ -231,15 +227,12 @@ __global__ __launch_bounds__(cxb_nw(NB, XT) * 64) void k_elbo_cxb(Lay l, const f
                 dst[MS + ms] = preb[u].x;
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const float x = c ? preb[u].x : prea[u].x;
-                    const unsigned b1 = __float_as_uint(x) & 0xFFFF0000u;
-                    const float r1 = x - __uint_as_float(b1);
-                    const unsigned b2 = __float_as_uint(r1) & 0xFFFF0000u;
-                    const float r2 = r1 - __uint_as_float(b2);
+                    unsigned b1, b2, b3;
+                    bf16_split3_rne(c ? preb[u].x : prea[u].x, &b1, &b2, &b3);   // (split once per symbol: rounded to nearest)
                     unsigned short* d = s_xb + c * 3 * MS + ms;
                     d[0] = (unsigned short)(b1 >> 16);
                     d[MS] = (unsigned short)(b2 >> 16);
-                    d[2 * MS] = (unsigned short)(__float_as_uint(r2) >> 16);
+                    d[2 * MS] = (unsigned short)(b3 >> 16);
                 }
                 dst[2 * MS + ms] = prea[u].y + preb[u].y;
                 dst[3 * MS + ms] = prea[u].y - preb[u].y;

@@ -12,6 +12,7 @@
 // Applies when mode = complex, l2 odd <= 79, l1 odd <= l2 and pad1 = l1 / 2 (lag rows in 1 .. 5 blocks of 16).
 #include <hip/hip_runtime.h>
 
+#include "v2vae_bf16_split.h"
 #include "v2vae_chain_cx.h"
 #include "v2vae_layout.h"
 
@@ -194,14 +195,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef short bfx8 __attribute__((ext_vector_type(8)));
 #define MFMA16BF(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bfx8, (a)), __builtin_bit_cast(bfx8, (b)), (c), 0, 0, 0)
 
-// the three bf16 pieces of x as the high halves of three words (low halves of the first two are zero)
-__device__ __forceinline__ void bf_split3(float x, unsigned* p1, unsigned* p2, unsigned* p3) {
-    const unsigned b1 = __float_as_uint(x) & 0xFFFF0000u;
-    const float r1 = x - __uint_as_float(b1);
-    const unsigned b2 = __float_as_uint(r1) & 0xFFFF0000u;
-    const float r2 = r1 - __uint_as_float(b2);
-    *p1 = b1; *p2 = b2; *p3 = __float_as_uint(r2);
-}
+// rho / sigma are split in registers, per (symbol, lag): by truncation (one AND per piece)
+__device__ __forceinline__ void bf_split3(float x, unsigned* p1, unsigned* p2, unsigned* p3) { bf16_split3_trunc(x, p1, p2, p3); }
 // (high half of lo, high half of hi) as one word of two bf16
 __device__ __forceinline__ unsigned bf_pack_hi(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
 // Words between the (copy, parity) regions of the planes of bf16 pairs: NPL piece planes and a pad of eight words.  The lanes
@@ -229,8 +224,9 @@ __device__ __forceinline__ void eqbf_load_tile(const Lay& l, const float* __rest
         dst[i] = v;
         const int e = SS == 1 ? i : i >> 1, par = SS == 1 ? 0 : i & 1;
         unsigned pc[6];
-        if (REAL) bf_split3(v.x, &pc[0], &pc[1], &pc[2]);
-        else { bf_split3(v.x, &pc[0], &pc[2], &pc[4]); bf_split3(v.y, &pc[1], &pc[3], &pc[5]); }
+        // (the samples are split once per tile: pieces rounded to nearest)
+        if (REAL) bf16_split3_rne(v.x, &pc[0], &pc[1], &pc[2]);
+        else { bf16_split3_rne(v.x, &pc[0], &pc[2], &pc[4]); bf16_split3_rne(v.y, &pc[1], &pc[3], &pc[5]); }
         // copy 0: element e is half e & 1 of word e >> 1, i.e. halfword e; copy 1 (pairs start at the odd elements): halfword e - 1
         unsigned short* d0 = Yh + 2 * ((0 * SS + par) * RS) + e;
         unsigned short* d1 = Yh + 2 * ((1 * SS + par) * RS) + e - 1;

@@ -7,7 +7,7 @@
 // multiply-adds per symbol - are a matrix product of the constant table with the sliding sample windows,
 //   [Re u; Im u] (32 rows = 16 lags) = [[K'r, -K'i], [K'i, K'r]] . [Ya; Yb],
 // formed by v_mfma_f32_32x32x16_bf16 with the symbols on the lanes: every float is the exact sum of three bf16 pieces (8 + 8 + 8
-// significand bits, by truncation) and the six piece products whose weight is not below 2^-24 of the whole are accumulated in
+// significand bits, each rounded to nearest) and the six piece products whose weight is not below 2^-24 of the whole are accumulated in
 // float, which is what the packed-float row sums of the vector-pipe kernel (k_eq_fwd_sym) amount to.  An f32 matrix instruction
 // would run at the vector rate and hold the vector pipe; a bf16 one runs at sixteen times that rate beside it.
 //   * lag rows in blocks of 16 (32 matrix rows: Re | Im); block row R needs the lag blocks g >= R only (upper triangle);
@@ -23,6 +23,7 @@
 //     its way into the equaliser gradients), rounded to float once.
 #include <hip/hip_runtime.h>
 
+#include "v2vae_bf16_split.h"
 #include "v2vae_cx_common.h"
 #include "v2vae_layout.h"
 
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(eqf_nw(NBK) * 64, NBK <= 2 ? 3 : 2) void k_eq_fwd_b
     typedef const unsigned __attribute__((address_space(3))) * lword_p;
     extern __shared__ __align__(16) float sm[];
     const u32x4* s_A = reinterpret_cast<const u32x4*>(sm);
-    // first-order weights as the accumulators start from them: [lag block R][lane half h][16] = (Re of lags 16 R + cx_kk(q, h),
+    // first-order weights in the order of the accumulator slots: [lag block R][lane half h][16] = (Re of lags 16 R + cx_kk(q, h),
     // q = 0..7 | Im of the same lags)
     const f32x4* s_k1 = reinterpret_cast<const f32x4*>(sm + NP * 1536);
     const int tlen = eqf_tlen(l, NBK), nwd = eqf_nwd(l, NBK), xh = eqf_xh(l, NBK);
@@ -99,15 +100,12 @@ __global__ __launch_bounds__(eqf_nw(NBK) * 64, NBK <= 2 ? 3 : 2) void k_eq_fwd_b
                 tile[e] = v;
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const float x = c ? v.y : v.x;
-                    const unsigned b1 = __float_as_uint(x) & 0xFFFF0000u;
-                    const float r1 = x - __uint_as_float(b1);
-                    const unsigned b2 = __float_as_uint(r1) & 0xFFFF0000u;
-                    const float r2 = r1 - __uint_as_float(b2);
+                    unsigned b1, b2, b3;
+                    bf16_split3_rne(c ? v.y : v.x, &b1, &b2, &b3);   // (split once per tile: pieces rounded to nearest)
                     unsigned short* d = Yh + 2 * (c * 3 * nwd) + e;
                     d[0] = (unsigned short)(b1 >> 16);
                     d[2 * nwd] = (unsigned short)(b2 >> 16);
-                    d[4 * nwd] = (unsigned short)(__float_as_uint(r2) >> 16);
+                    d[4 * nwd] = (unsigned short)(b3 >> 16);
                 }
             }
         }
@@ -128,18 +126,13 @@ __global__ __launch_bounds__(eqf_nw(NBK) * 64, NBK <= 2 ? 3 : 2) void k_eq_fwd_b
         typedef const u32x4 __attribute__((address_space(3))) * lvec_p;
         lvec_p At = (lvec_p)s_A + lane;
         asm volatile("" : "+v"(At));
-        // the accumulators start from the first-order weights of their lags (added to the row sums for nothing)
         f32x16 acc[CT][NBK];
 #pragma unroll
-        for (int R = 0; R < NBK; ++R) {
-            f32x4 kw[4];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) kw[v] = s_k1[(R * 2 + h) * 4 + v];
+        for (int R = 0; R < NBK; ++R)
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) acc[ct][R][q] = kw[q >> 2][q & 3];
-        }
+                for (int q = 0; q < 16; ++q) acc[ct][R][q] = 0.f;
         const int t00 = (64 * wv + 32 * ct0 + i) * S + C0 - 8 * h - 7;   // first sample of the lane's operand of lag block 0, first column tile
         const unsigned sh = (t00 & 1) * 16;                    // (zero at two samples per symbol: the tile origin sees to that)
         // table fragments of step n + 1 (a step = one (lag block g, stream c, block row R <= g)) are requested before the matrix
@@ -197,27 +190,38 @@ __global__ __launch_bounds__(eqf_nw(NBK) * 64, NBK <= 2 ? 3 : 2) void k_eq_fwd_b
         }
 
         // ---- closing stage: accumulator slot q of lane half h holds lag 16 R + cx_kk(q, h) (Re in slot q, Im in slot q + 8)
+        double outr[CT], outi[CT];
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            double outr = 0.0, outi = 0.0;
-            const f2* ys = tile + (64 * wv + 32 * (ct0 + ct) + i) * S + C0;
+        for (int ct = 0; ct < CT; ++ct) { outr[ct] = 0.0; outi[ct] = 0.0; }
 #pragma unroll
-            for (int R = 0; R < NBK; ++R)
+        for (int R = 0; R < NBK; ++R) {
+            // (the first-order weight - the centre one is the largest number of the whole sum - joins the FINISHED row sum, one
+            // rounding at its size; as the start value of the accumulator it would take one rounding per matrix instruction of
+            // the row, 12 per lag block, and left 2e-7 of relative error in xhat)
+            f32x4 kw[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) kw[v] = s_k1[(R * 2 + h) * 4 + v];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const f2* ys = tile + (64 * wv + 32 * (ct0 + ct) + i) * S + C0;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int a = 16 * R + cx_kk(q, h);
                     const f2 yv = ys[-a];
-                    const float ur = acc[ct][R][q], ui = acc[ct][R][q + 8];
+                    const float ur = acc[ct][R][q] + kw[q >> 2][q & 3], ui = acc[ct][R][q + 8] + kw[2 + (q >> 2)][q & 3];
                     const float tr = fmaf(-ui, yv.y, ur * yv.x), ti = fmaf(ui, yv.x, ur * yv.y);
-                    outr += (double)tr;
-                    outi += (double)ti;
+                    outr[ct] += (double)tr;
+                    outi[ct] += (double)ti;
                 }
-            outr += __shfl_xor(outr, 32);
-            outi += __shfl_xor(outi, 32);
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const double sr = outr[ct] + __shfl_xor(outr[ct], 32), si = outi[ct] + __shfl_xor(outi[ct], 32);
             const int64_t b = b0 + 64 * wv + 32 * (ct0 + ct) + i;
             if (h == 0 && b < sym_hi) {
-                xhat[b - l.sym_lo] = (float)outr;
-                xhat[l.sym_cnt + (b - l.sym_lo)] = (float)outi;
+                xhat[b - l.sym_lo] = (float)sr;
+                xhat[l.sym_cnt + (b - l.sym_lo)] = (float)si;
             }
         }
         }

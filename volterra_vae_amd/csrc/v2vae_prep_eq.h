@@ -4,6 +4,7 @@
 #define V2VAE_PREP_EQ_H
 #include <hip/hip_runtime.h>
 
+#include "v2vae_bf16_split.h"
 #include "v2vae_layout.h"
 
 namespace v2vae {
@@ -42,7 +43,7 @@ __device__ __forceinline__ void d_prep_eqcxb(const Lay& l, const float* __restri
         // table images of the forward on the bf16 matrix pipe (k_eq_fwd_bf): [pairs (R, g >= R)][stream c][piece][64 lanes][4 words
         // of two bf16].  Lane (jj, hh): matrix row jj = (Re | Im of u, lag a = 16 R + (jj & 15)); element j of the lane is the
         // k-slot of lag b = 16 g + 8 hh + 7 - j of stream c.  Entry: [[K'r, -K'i], [K'i, K'r]] with K'_ab = K_ab (a = b),
-        // 2 K_ab (a < b), 0 (a > b, or a lag from l2 on), K = k2 + k2^T; each float as three exact bf16 pieces (by truncation).
+        // 2 K_ab (a < b), 0 (a > b, or a lag from l2 on), K = k2 + k2^T; each float as three exact bf16 pieces (rounded to nearest).
         const int NBK = l.eqfbf_nbk, NPW = NBK * (NBK + 1) / 2 * 1536;
         for (int idx = bid * NT + threadIdx.x; idx < NPW; idx += nb * NT) {
             const int w = idx & 3, ln = (idx >> 2) & 63, pc = (idx >> 8) % 3, c = (idx / 768) & 1;
@@ -59,12 +60,7 @@ __device__ __forceinline__ void d_prep_eqcxb(const Lay& l, const float* __restri
                     const float kr = sc * (k2r[a * l2 + b] + k2r[b * l2 + a]), ki = sc * (k2i[a * l2 + b] + k2i[b * l2 + a]);
                     t = c == 0 ? (cjj == 0 ? kr : ki) : (cjj == 0 ? -ki : kr);
                 }
-                unsigned bits = 0;
-                for (int q = 0; q <= pc; ++q) {   // piece pc of t: truncate, subtract, repeat
-                    bits = __float_as_uint(t) & 0xFFFF0000u;
-                    t -= __uint_as_float(bits);
-                }
-                word |= (bits >> 16) << (16 * u);
+                word |= bf16_piece_rne(t, pc) << (16 * u);   // (split once per step: pieces rounded to nearest)
             }
             ws[l.o_eqfbf + idx] = __uint_as_float(word);
         }
