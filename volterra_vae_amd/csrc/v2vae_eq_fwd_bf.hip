@@ -18,6 +18,10 @@
 //   * A operand: the table pieces, LDS-resident for the whole launch, one 16-byte read per lane and matrix instruction pair:
 //     a wave works on two column tiles of 32 symbols at a time, so every table fragment read serves two matrix instructions
 //     and every sample fragment all block rows R <= g;
+//   * a lag count of the form 16 NBK + 1 (65 lags: the configuration of the long-channel benchmark) would spend a whole block
+//     row and column - NBK + 1 of the (NBK + 1)(NBK + 2) / 2 block pairs - on one lag.  The XL = 1 instances keep NBK blocks on the
+//     matrix pipe and carry lag e = 16 NBK on the side, in the closing stage: u_a += K'_ae y_e for every row a < e (one complex
+//     multiply-add on the vector pipe per row), and row e itself is the single product K'_ee y_e;
 //   * the closing stage stays what it was: first-order weight added to the finished row sum, the row's product with y_a in
 //     float, the sum over the rows in double (the soft demapper amplifies an error of xhat by 2 |xhat - a| / noise variance on
 //     its way into the equaliser gradients), rounded to float once.
@@ -40,13 +44,15 @@ V2VAE_HD constexpr int eqf_ct(int nbk) { return nbk <= 4 ? 2 : 1; }
 V2VAE_HD inline int eqf_xh(const Lay& l, int nbk) { return 16 * nbk + ((l.hl + l.p2 + 1) & 1); }
 V2VAE_HD inline int eqf_tlen(const Lay& l, int nbk) { return 64 * eqf_nw(nbk) * l.S + l.hl + l.hr + 1 + eqf_xh(l, nbk); }
 V2VAE_HD inline int eqf_nwd(const Lay& l, int nbk) { return (eqf_tlen(l, nbk) + 1) / 2 + 4; }
+// floats of the side lag's table: K'_ae for the 16 NBK rows in accumulator-slot order, then (K'_ee, first-order weight of lag e)
+V2VAE_HD constexpr int eqf_xl_floats(int nbk, int xl) { return xl ? 32 * nbk + 4 : 0; }
 V2VAE_HD inline int eqf_lds_floats(const Lay& l, int nbk) {
-    return nbk * (nbk + 1) / 2 * 1536 + 32 * nbk + 2 * eqf_tlen(l, nbk) + 6 * eqf_nwd(l, nbk);
+    return nbk * (nbk + 1) / 2 * 1536 + 32 * nbk + eqf_xl_floats(nbk, l.eqfbf_xl) + 2 * eqf_tlen(l, nbk) + 6 * eqf_nwd(l, nbk);
 }
 
 // LDS (floats): table images [pairs (R, g >= R)][2 streams][3 pieces][64 lanes][4 words] | first-order weights [16 NBK][2] |
-// sample tile [tlen][2] | bf16 planes [2 streams][3 pieces][nwd words]
-template <int NBK, int SS>
+// XL: side-lag column [16 NBK][2] and four scalars | sample tile [tlen][2] | bf16 planes [2 streams][3 pieces][nwd words]
+template <int NBK, int SS, int XL>
 __global__ __launch_bounds__(eqf_nw(NBK) * 64, NBK <= 2 ? 3 : 2) void k_eq_fwd_bf(Lay l, const float* __restrict__ y, const float* __restrict__ ws,
                                                                           float* __restrict__ xhat) {
     constexpr int NP = NBK * (NBK + 1) / 2, EQF_NW = eqf_nw(NBK), NTH = EQF_NW * 64, EQF_NSYM = 64 * EQF_NW, S = SS, CT = eqf_ct(NBK);
@@ -57,8 +63,12 @@ __global__ __launch_bounds__(eqf_nw(NBK) * 64, NBK <= 2 ? 3 : 2) void k_eq_fwd_b
     // q = 0..7 | Im of the same lags)
     const f32x4* s_k1 = reinterpret_cast<const f32x4*>(sm + NP * 1536);
     const int tlen = eqf_tlen(l, NBK), nwd = eqf_nwd(l, NBK), xh = eqf_xh(l, NBK);
-    f2* tile = reinterpret_cast<f2*>(sm + NP * 1536 + 32 * NBK);
-    unsigned* Yw = reinterpret_cast<unsigned*>(sm + NP * 1536 + 32 * NBK + 2 * tlen);
+    constexpr int XLF = eqf_xl_floats(NBK, XL);
+    // XL: column e = 16 NBK of K' in the order of the accumulator slots, [lag block R][lane half h][16] like the first-order
+    // weights, then K'_ee (Re, Im) and the first-order weight of lag e (Re, Im)
+    const f32x4* s_xl = reinterpret_cast<const f32x4*>(sm + NP * 1536 + 32 * NBK);
+    f2* tile = reinterpret_cast<f2*>(sm + NP * 1536 + 32 * NBK + XLF);
+    unsigned* Yw = reinterpret_cast<unsigned*>(sm + NP * 1536 + 32 * NBK + XLF + 2 * tlen);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, i = lane & 31, h = lane >> 5;
     const int64_t sym_hi = l.sym_lo + l.sym_cnt;
     const int64_t ntile = (l.sym_cnt + EQF_NSYM - 1) / EQF_NSYM;
@@ -68,6 +78,14 @@ __global__ __launch_bounds__(eqf_nw(NBK) * 64, NBK <= 2 ? 3 : 2) void k_eq_fwd_b
     for (int idx = tid; idx < 32 * NBK; idx += NTH) {
         const int q = idx & 15, hh = (idx >> 4) & 1, R = idx >> 5;
         sm[NP * 1536 + idx] = ws[l.o_eqfbf + NP * 1536 + 2 * (16 * R + cx_kk(q & 7, hh)) + (q >> 3)];
+    }
+    if (XL) {
+        const float* src = ws + l.o_eqfbf + NP * 1536 + 32 * NBK;   // [16 NBK][2], then the four scalars
+        for (int idx = tid; idx < 32 * NBK; idx += NTH) {
+            const int q = idx & 15, hh = (idx >> 4) & 1, R = idx >> 5;
+            sm[NP * 1536 + 32 * NBK + idx] = src[2 * (16 * R + cx_kk(q & 7, hh)) + (q >> 3)];
+        }
+        if (tid < 4) sm[NP * 1536 + 64 * NBK + tid] = src[32 * NBK + tid];
     }
     for (int idx = tid; idx < 6 * nwd; idx += NTH) Yw[idx] = 0u;
 
@@ -198,21 +216,41 @@ __global__ __launch_bounds__(eqf_nw(NBK) * 64, NBK <= 2 ? 3 : 2) void k_eq_fwd_b
             // (the first-order weight - the centre one is the largest number of the whole sum - joins the FINISHED row sum, one
             // rounding at its size; as the start value of the accumulator it would take one rounding per matrix instruction of
             // the row, 12 per lag block, and left 2e-7 of relative error in xhat)
-            f32x4 kw[4];
+            f32x4 kw[4], kx[4];
 #pragma unroll
-            for (int v = 0; v < 4; ++v) kw[v] = s_k1[(R * 2 + h) * 4 + v];
+            for (int v = 0; v < 4; ++v) {
+                kw[v] = s_k1[(R * 2 + h) * 4 + v];
+                if (XL) kx[v] = s_xl[(R * 2 + h) * 4 + v];
+            }
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 const f2* ys = tile + (64 * wv + 32 * (ct0 + ct) + i) * S + C0;
+                const f2 ye = XL ? ys[-16 * NBK] : f2{0.f, 0.f};
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int a = 16 * R + cx_kk(q, h);
                     const f2 yv = ys[-a];
-                    const float ur = acc[ct][R][q] + kw[q >> 2][q & 3], ui = acc[ct][R][q + 8] + kw[2 + (q >> 2)][q & 3];
+                    float sr = acc[ct][R][q], si = acc[ct][R][q + 8];
+                    if (XL) {   // the side lag's term of the row sum: K'_ae y_e
+                        const float xr = kx[q >> 2][q & 3], xi = kx[2 + (q >> 2)][q & 3];
+                        sr = fmaf(-xi, ye.y, fmaf(xr, ye.x, sr));
+                        si = fmaf(xi, ye.x, fmaf(xr, ye.y, si));
+                    }
+                    const float ur = sr + kw[q >> 2][q & 3], ui = si + kw[2 + (q >> 2)][q & 3];
                     const float tr = fmaf(-ui, yv.y, ur * yv.x), ti = fmaf(ui, yv.x, ur * yv.y);
                     outr[ct] += (double)tr;
                     outi[ct] += (double)ti;
                 }
+            }
+        }
+        if (XL && h == 0) {   // row e: u_e = K'_ee y_e, its first-order weight, its product with y_e
+            const f32x4 ke = *reinterpret_cast<const f32x4*>(sm + NP * 1536 + 64 * NBK);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const f2 ye = tile[(64 * wv + 32 * (ct0 + ct) + i) * S + C0 - 16 * NBK];
+                const float ur = fmaf(-ke[1], ye.y, ke[0] * ye.x) + ke[2], ui = fmaf(ke[1], ye.x, ke[0] * ye.y) + ke[3];
+                outr[ct] += (double)fmaf(-ui, ye.y, ur * ye.x);
+                outi[ct] += (double)fmaf(ui, ye.x, ur * ye.y);
             }
         }
 #pragma unroll
@@ -228,7 +266,7 @@ __global__ __launch_bounds__(eqf_nw(NBK) * 64, NBK <= 2 ? 3 : 2) void k_eq_fwd_b
     }
 }
 
-template <int NBK>
+template <int NBK, int XL>
 static int launch_eqf(const Lay& l, const float* y, const float* ws, float* xhat, hipStream_t st) {
     constexpr int EQF_NW = eqf_nw(NBK), EQF_NSYM = 64 * EQF_NW;
     const int lds = eqf_lds_floats(l, NBK) * 4;
@@ -239,10 +277,10 @@ static int launch_eqf(const Lay& l, const float* y, const float* ws, float* xhat
     const int nb = (int)(ntile < (int64_t)per_cu * 256 ? ntile : (int64_t)per_cu * 256);
 #define V2VAE_EQF(SS)                                                                                                       \
     do {                                                                                                                    \
-        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k_eq_fwd_bf<NBK, SS>),                      \
+        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k_eq_fwd_bf<NBK, SS, XL>),                      \
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)          \
             return V2VAE_ELAUNCH;                                                                                           \
-        hipLaunchKernelGGL((k_eq_fwd_bf<NBK, SS>), dim3(nb), dim3(EQF_NW * 64), lds, st, l, y, ws, xhat);                    \
+        hipLaunchKernelGGL((k_eq_fwd_bf<NBK, SS, XL>), dim3(nb), dim3(EQF_NW * 64), lds, st, l, y, ws, xhat);                    \
     } while (0)
     if (l.S == 1) V2VAE_EQF(1);
     else V2VAE_EQF(2);
@@ -253,13 +291,20 @@ static int launch_eqf(const Lay& l, const float* y, const float* ws, float* xhat
 int eq_fwd_bf_lds_bytes(const Lay& l) { return eqf_lds_floats(l, l.eqfbf_nbk) * 4; }
 
 int launch_eq_fwd_bf(const Lay& l, const float* y, const float* ws, float* xhat, hipStream_t st) {
+    if (l.eqfbf_xl) {   // 16 NBK + 1 lags: NBK blocks and the lag on the side
+        switch (l.eqfbf_nbk) {
+            case 2: return launch_eqf<2, 1>(l, y, ws, xhat, st);
+            case 3: return launch_eqf<3, 1>(l, y, ws, xhat, st);
+            case 4: return launch_eqf<4, 1>(l, y, ws, xhat, st);
+            case 5: return launch_eqf<5, 1>(l, y, ws, xhat, st);
+            default: return V2VAE_ESIZE;
+        }
+    }
     switch (l.eqfbf_nbk) {
-        case 1: return launch_eqf<1>(l, y, ws, xhat, st);
-        case 2: return launch_eqf<2>(l, y, ws, xhat, st);
-        case 3: return launch_eqf<3>(l, y, ws, xhat, st);
-        case 4: return launch_eqf<4>(l, y, ws, xhat, st);
-        case 5: return launch_eqf<5>(l, y, ws, xhat, st);
-        case 6: return launch_eqf<6>(l, y, ws, xhat, st);
+        case 3: return launch_eqf<3, 0>(l, y, ws, xhat, st);
+        case 4: return launch_eqf<4, 0>(l, y, ws, xhat, st);
+        case 5: return launch_eqf<5, 0>(l, y, ws, xhat, st);
+        case 6: return launch_eqf<6, 0>(l, y, ws, xhat, st);
         default: return V2VAE_ESIZE;
     }
 }

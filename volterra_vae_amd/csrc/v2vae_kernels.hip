@@ -283,10 +283,13 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     l.o_eqsym = take(l.eqsym_t ? l.eqsym_t * (l.eqsym_t + 1) + 2 * l.eqsym_t + 16 : 0);
     // (from three blocks of 16 lags on: up to 31 lags the symmetric form on the vector pipe is ahead, 0.130 against 0.150 ms per
     // 2^22 symbols at 25 lags - there the closing stage, which the two share, is as long as the row sums)
-    l.eqfbf_nbk = (l.l2 + 15) / 16;
-    l.eqfbf = (l.mode == 1 && l.eqsym_t && !l.eqsymr && l.S <= 2 && l.eqfbf_nbk >= 3 &&
+    // (16 NBK + 1 lags: NBK blocks on the matrix pipe and the last lag on the side, in the closing stage)
+    l.eqfbf_xl = (l.l2 > 32 && l.l2 % 16 == 1) ? 1 : 0;
+    l.eqfbf_nbk = l.eqfbf_xl ? l.l2 / 16 : (l.l2 + 15) / 16;
+    l.eqfbf = (l.mode == 1 && l.eqsym_t && !l.eqsymr && l.S <= 2 && l.eqfbf_nbk + l.eqfbf_xl >= 3 &&
                !(l.flags & (V2VAE_FLAG_F32_MATRIX | V2VAE_FLAG_EQ_MFMA_FWD))) ? 1 : 0;
-    l.o_eqfbf = take(l.eqfbf ? (int64_t)(l.eqfbf_nbk * (l.eqfbf_nbk + 1) / 2) * 1536 + 32 * l.eqfbf_nbk : 0);
+    l.o_eqfbf = take(l.eqfbf ? (int64_t)(l.eqfbf_nbk * (l.eqfbf_nbk + 1) / 2) * 1536 + 32 * l.eqfbf_nbk +
+                                   (l.eqfbf_xl ? 32 * l.eqfbf_nbk + 4 : 0) : 0);
     l.o_part_eqcxb = take((l.use_eqcxb && !l.eqb16) ? (int64_t)l.nblk_eq * l.eqcxb_rec : 0);
     l.o_tot_eqcxb = take((l.use_eqcxb && !l.eqb16) ? l.eqcxb_rec : 0);
     {

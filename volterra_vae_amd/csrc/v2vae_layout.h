@@ -108,8 +108,10 @@ struct Lay {
     int64_t o_eqsym;
     // forward of the complex equaliser on the bf16 matrix pipe in split arithmetic (k_eq_fwd_bf: one or two samples per symbol,
     // up to 95 lags): eqfbf_nbk blocks of 16 lags; at o_eqfbf the table images [pairs (R, g >= R)][2 streams][3 pieces][64 lanes]
-    // [8 bf16], then the first-order weights on lag indices [16 eqfbf_nbk][2]
-    int eqfbf, eqfbf_nbk;
+    // [8 bf16], then the first-order weights on lag indices [16 eqfbf_nbk][2]; eqfbf_xl: the lag count is 16 eqfbf_nbk + 1 and
+    // the last lag e is carried on the side - behind the weights then column e of K' [16 eqfbf_nbk][2], K'_ee and the first-order
+    // weight of lag e
+    int eqfbf, eqfbf_nbk, eqfbf_xl;
     int64_t o_eqfbf;
     int64_t o_sumstage;      // 3 x [SUM_CHUNKS][largest record] staging of the two-stage record sums (one per record set)
     int64_t sumstage_stride; // floats between the three staging areas

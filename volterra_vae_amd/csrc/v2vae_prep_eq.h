@@ -69,6 +69,21 @@ __device__ __forceinline__ void d_prep_eqcxb(const Lay& l, const float* __restri
             const int jj = p1 + p2 - a;  // first-order tap that multiplies lag a
             ws[l.o_eqfbf + NPW + idx] = (a < l2 && jj >= 0 && jj < l1) ? (plane == 0 ? k1r[jj] : k1i[jj]) : 0.f;
         }
+        if (l.eqfbf_xl) {   // the lag on the side, e = 16 NBK = l2 - 1: K'_ae = 2 K_ae for the rows a < e, then K'_ee and lag e's weight
+            const int e = 16 * NBK;
+            for (int idx = bid * NT + threadIdx.x; idx < 32 * NBK + 4; idx += nb * NT) {
+                float v;
+                if (idx < 32 * NBK) {
+                    const int a = idx >> 1;
+                    v = 2.f * ((idx & 1) ? k2i[a * l2 + e] + k2i[e * l2 + a] : k2r[a * l2 + e] + k2r[e * l2 + a]);
+                } else {
+                    const int q = idx - 32 * NBK, jj = p1 + p2 - e;
+                    if (q < 2) v = q ? 2.f * k2i[e * l2 + e] : 2.f * k2r[e * l2 + e];   // K_ee = k2_ee + k2_ee
+                    else v = (jj >= 0 && jj < l1) ? (q == 2 ? k1r[jj] : k1i[jj]) : 0.f;
+                }
+                ws[l.o_eqfbf + NPW + 32 * NBK + idx] = v;
+            }
+        }
     }
     if (l.eqsym_t) {   // table of the symmetric-form forward kernel (k_eq_fwd_sym): one stream of (Re, Im) entries, row after row,
                        // row a = [K'_aa, K'_a,a+1, ..., K'_a,T-1, first-order weight of lag a]; eight zero entries pad the end
