@@ -377,12 +377,14 @@ def test_run_and_block_tile_elbo_kernels_agree(L, S, B):
 
 
 @pytest.mark.parametrize("L,S,l2,B", [(25, 2, 25, 5000), (25, 2, 25, 333), (9, 1, 15, 2049), (25, 2, 47, 1500), (9, 2, 65, 1300),
-                                      (13, 1, 79, 900), (9, 2, 31, 257)])
+                                      (13, 1, 79, 900), (9, 2, 31, 257), (9, 2, 17, 700), (9, 1, 17, 333), (9, 1, 33, 500),
+                                      (9, 2, 49, 450), (9, 1, 65, 300), (9, 1, 81, 300)])
 def test_split_bf16_and_f32_matrix_routes_agree(L, S, l2, B):
     """Complex model: the equaliser forward and backward (and, up to 16 active taps per phase, the H X and H w products of the run
     ELBO kernel) on bf16 matrix instructions in three-piece split arithmetic - the default - against the same sums on the vector
-    pipe / on f32 matrix instructions (V2VAE_FLAG_F32_MATRIX): different programs, both exact to float rounding, at 1 ... 5
-    blocks of 16 lags, one and two samples per symbol, tiles that end inside a block of 32 symbols."""
+    pipe / on f32 matrix instructions (V2VAE_FLAG_F32_MATRIX): different programs, both exact to float rounding, at 1 ... 6
+    blocks of 16 lags, one and two samples per symbol, tiles that end inside a block of 32 symbols; lag counts 16 k + 1, whose
+    last lag (and, in the backward, the column of ones behind it) the bf16 kernels carry on the side of k blocks."""
     from volterra_vae_amd import _lib
     from volterra_vae_amd.ops import Plan
     l1 = l2 if l2 <= 25 else 25

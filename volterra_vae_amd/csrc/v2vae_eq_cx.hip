@@ -190,6 +190,11 @@ __global__ __launch_bounds__(NT, NB16 <= 3 ? 4 : 2) void k_eq_bwd_cx(Lay l, cons
 //   formed in float from the float tile and split in registers (plain vector instructions: they run beside the matrix pipe).
 //   dK_r = sum rho^T Ya + sigma^T Yb,  dK_i = sum sigma^T Ya + (-rho)^T Yb: four products of 6 matrix instructions per
 //   16x16 block pair and 32 symbols.
+//   Columns on the side (XS = 1): with 16 k + 1 lags (the lag count is odd) the one lag beyond the k blocks and the column of
+//   ones behind the lags (whose sums are the first-order gradient) would take a whole block row and column, k + 1 of the
+//   (k + 1)(k + 2) / 2 block pairs.  Those instances keep NB16 = k blocks on the matrix pipe and form the two extra columns per
+//   lane on the vector pipe from the rho / sigma it holds in float anyway (two additions, four multiply-adds per symbol and
+//   row), and row e of the extra lag likewise; the record keeps its k + 1 blocks.
 // ------------------------------------------------------------------------------------------------------------
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef short bfx8 __attribute__((ext_vector_type(8)));
@@ -263,10 +268,15 @@ __device__ __forceinline__ void eqbf_load_tile(const Lay& l, const float* __rest
 // LDS (floats): sample tile [tile_len][2] | (g0, g1) per symbol [EQ_TB] | constant (1, 0) samples [64 S][2] | planes of bf16
 // pairs [2 copies][S parities] regions of [NPL][EQBF_NWD] words (+ pad) | one constant region (lag columns from l2 on: Ya
 // pieces (1, 0, 0), Yb pieces 0)
-template <int NB16, int SS, bool REAL>
-__global__ __launch_bounds__(NT, NB16 <= 2 ? 4 : NB16 == 3 ? 3 : 2) void k_eq_bwd_bf(Lay l, const float* __restrict__ y, const float* __restrict__ gx,
+// XS: -1 = every column in the blocks; 1 = 16 NB16 + 1 lags, the last lag e = 16 NB16 and the column of ones on the side
+// (0 = the column of ones alone on the side: no supported lag count needs it, the lag count is odd)
+// (waves per SIMD by register need; the extra lag's samples and sums take about 20 + 4 NB16 registers)
+__host__ __device__ constexpr int eqbf_waves(int nb16, int xs) { return xs == 1 ? (nb16 <= 2 ? 3 : 2) : (nb16 <= 2 ? 4 : nb16 == 3 ? 3 : 2); }
+template <int NB16, int SS, bool REAL, int XS>
+__global__ __launch_bounds__(NT, eqbf_waves(NB16, XS)) void k_eq_bwd_bf(Lay l, const float* __restrict__ y, const float* __restrict__ gx,
                                                                   float* __restrict__ ws) {
-    constexpr int NBLK = NB16 * (NB16 + 1) / 2, LD = 16 * NB16, S = SS, NPL = REAL ? 3 : 6, nwd = EQBF_NWD, RS = eqbf_rs<REAL>();
+    constexpr int NBLK = NB16 * (NB16 + 1) / 2, LD = 16 * (NB16 + (XS >= 0 ? 1 : 0)), S = SS, NPL = REAL ? 3 : 6, nwd = EQBF_NWD, RS = eqbf_rs<REAL>();
+    constexpr int EX = 16 * NB16;   // XS = 1: the lag on the side
     static_assert(SS == 1 || SS == 2, "parity planes for one or two samples per symbol");
     typedef float f2 __attribute__((ext_vector_type(2)));
     typedef const unsigned __attribute__((address_space(3))) * lword_p;
@@ -284,6 +294,18 @@ __global__ __launch_bounds__(NT, NB16 <= 2 ? 4 : NB16 == 3 ? 3 : 2) void k_eq_bw
     for (int q = 0; q < NBLK; ++q)
 #pragma unroll
         for (int g = 0; g < 4; ++g) { Ar[q][g] = 0.f; Ai[q][g] = 0.f; }
+    // columns on the side: per lane and row block the sums over this lane's symbols of (rho, sigma) - the column of ones - and
+    // of (rho + i sigma) paired with the samples of lag e; row e: its (e, e) and (e, ones) entries
+    // Plain floats, and after every update each sum is made opaque to the compiler, so that it stays a chain of single-width
+    // instructions of its own: left alone the compiler pairs these loop-carried sums into packed instructions (v_pk_fma_f32 /
+    // v_pk_add_f32 with operand selects) between the bf16 matrix instructions, and the sums so formed came out different from run
+    // to run (the entries of column e, nothing else; every variant that kept them unpacked was bitwise reproducible and right).
+    float s1r[XS >= 0 ? NB16 : 1], s1i[XS >= 0 ? NB16 : 1], ser[XS == 1 ? NB16 : 1], sei[XS == 1 ? NB16 : 1];
+    float reer = 0.f, reei = 0.f, re1r = 0.f, re1i = 0.f;
+#pragma unroll
+    for (int ib = 0; ib < (XS >= 0 ? NB16 : 1); ++ib) { s1r[ib] = 0.f; s1i[ib] = 0.f; }
+#pragma unroll
+    for (int ib = 0; ib < (XS == 1 ? NB16 : 1); ++ib) { ser[ib] = 0.f; sei[ib] = 0.f; }
     for (int idx = tid; idx < 128 * S; idx += NT) sm[o_ones + idx] = (idx & 1) ? 0.f : 1.f;
     for (int idx = tid; idx < 2 * S * RS; idx += NT) Yw[idx] = 0u;
     for (int idx = tid; idx < RS; idx += NT) Yc[idx] = idx < nwd ? 0x3F803F80u : 0u;
@@ -317,6 +339,34 @@ __global__ __launch_bounds__(NT, NB16 <= 2 ? 4 : NB16 == 3 ? 3 : 2) void k_eq_bw
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const f32x4* g4 = reinterpret_cast<const f32x4*>(g2 + wv * 64 + 32 * s + 8 * kq);   // (g0, g1) of two symbols per read
+            float yex[XS == 1 ? 8 : 1], yey[XS == 1 ? 8 : 1];
+            if (XS == 1) {   // the samples of the lane's eight symbols at lag e, and row e's own sums
+                const f2* pe = reinterpret_cast<const f2*>(tile) + (wv * 64 + 8 * kq + 32 * s) * S + l.hl + l.p2 - EX;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const f2 v = pe[k * S];
+                    yex[k] = v.x; yey[k] = v.y;
+                }
+#pragma unroll
+                for (int k2 = 0; k2 < 4; ++k2) {
+                    const f32x4 gg = g4[k2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const float xx = yex[2 * k2 + u], xy = yey[2 * k2 + u];
+                        const float g0 = gg[2 * u], g1 = gg[2 * u + 1];
+                        const float r = REAL ? g0 * xx : fmaf(g1, xy, g0 * xx);
+                        const float sg = REAL ? 0.f : fmaf(g1, xx, -(g0 * xy));
+                        re1r += r;
+                        re1i += sg;
+                        reer = fmaf(sg, xy, fmaf(r, xx, reer));
+                        if (!REAL) reei = fmaf(-r, xy, fmaf(sg, xx, reei));
+                        asm volatile("" : "+v"(reer));
+                        asm volatile("" : "+v"(reei));
+                        asm volatile("" : "+v"(re1r));
+                        asm volatile("" : "+v"(re1i));
+                    }
+                }
+            }
 #pragma unroll
             for (int ib = 0; ib < NB16; ++ib) {
                 // ---- A operands of block ib: rho, sigma, -rho in three pieces each, two symbols per word (plain vector
@@ -333,9 +383,21 @@ __global__ __launch_bounds__(NT, NB16 <= 2 ? 4 : NB16 == 3 ? 3 : 2) void k_eq_bw
                         const float g0 = gg[2 * u], g1 = gg[2 * u + 1];
                         const float r = REAL ? g0 * x.x : fmaf(g1, x.y, g0 * x.x);
                         bf_split3(r, &pr[u][0], &pr[u][1], &pr[u][2]);
-                        if (!REAL) {
-                            const float sg = fmaf(g1, x.x, -(g0 * x.y));
-                            bf_split3(sg, &ps[u][0], &ps[u][1], &ps[u][2]);
+                        const float sg = REAL ? 0.f : fmaf(g1, x.x, -(g0 * x.y));
+                        if (!REAL) bf_split3(sg, &ps[u][0], &ps[u][1], &ps[u][2]);
+                        if (XS >= 0) {
+                            s1r[ib] += r; s1i[ib] += sg;
+                            if (XS == 0) { asm volatile("" : "+v"(s1r[ib])); asm volatile("" : "+v"(s1i[ib])); }
+                        }
+                        if (XS == 1) {
+                            const float vx = yex[k], vy = yey[k];
+                            ser[ib] = fmaf(sg, vy, fmaf(r, vx, ser[ib]));
+                            if (!REAL) sei[ib] = fmaf(-r, vy, fmaf(sg, vx, sei[ib]));
+                            // (each sum kept a single-width chain of its own: see the note at the declarations)
+                            asm volatile("" : "+v"(ser[ib]));
+                            asm volatile("" : "+v"(sei[ib]));
+                            asm volatile("" : "+v"(s1r[ib]));
+                            asm volatile("" : "+v"(s1i[ib]));
                         }
                     }
 #pragma unroll
@@ -396,6 +458,33 @@ __global__ __launch_bounds__(NT, NB16 <= 2 ? 4 : NB16 == 3 ? 3 : 2) void k_eq_bw
                         if (!REAL) img[LD * LD + e] += Ai[q][g];
                     }
                 }
+            if (XS >= 0) {   // the columns on the side: the four symbol groups of the wave added on the vector pipe, lanes 0-15 write
+#pragma unroll
+                for (int ib = 0; ib < NB16; ++ib) {
+                    float ax = s1r[ib], ay = s1i[ib], bx = XS == 1 ? ser[ib] : 0.f, by = XS == 1 ? sei[ib] : 0.f;
+                    ax += __shfl_xor(ax, 16); ay += __shfl_xor(ay, 16); bx += __shfl_xor(bx, 16); by += __shfl_xor(by, 16);
+                    ax += __shfl_xor(ax, 32); ay += __shfl_xor(ay, 32); bx += __shfl_xor(bx, 32); by += __shfl_xor(by, 32);
+                    if (lane < 16) {
+                        const int row = (16 * ib + lane) * LD;
+                        img[row + EX + XS] += ax;
+                        if (!REAL) img[LD * LD + row + EX + XS] += ay;
+                        if (XS == 1) {
+                            img[row + EX] += bx;
+                            if (!REAL) img[LD * LD + row + EX] += by;
+                        }
+                    }
+                }
+                if (XS == 1) {   // row e (the sixteen lanes of a symbol group hold the same sums: one of them counts)
+                    float ax = re1r, ay = re1i, bx = reer, by = reei;
+                    ax += __shfl_xor(ax, 16); ay += __shfl_xor(ay, 16); bx += __shfl_xor(bx, 16); by += __shfl_xor(by, 16);
+                    ax += __shfl_xor(ax, 32); ay += __shfl_xor(ay, 32); bx += __shfl_xor(bx, 32); by += __shfl_xor(by, 32);
+                    if (lane == 0) {
+                        img[EX * LD + EX + 1] += ax;
+                        img[EX * LD + EX] += bx;
+                        if (!REAL) { img[LD * LD + EX * LD + EX + 1] += ay; img[LD * LD + EX * LD + EX] += by; }
+                    }
+                }
+            }
         }
         __syncthreads();
     }
@@ -430,27 +519,43 @@ int launch_eq_bwd_cx(const Lay& l, const float* y, const float* gx, float* ws, h
         else V2VAE_LAUNCH_EQB16_S(NB, 0);            \
     } while (0)
     if (l.eqbf) {
-#define V2VAE_LAUNCH_EQBF_R(NB, SS, RR)                                                                                          \
+#define V2VAE_LAUNCH_EQBF_R(NB, SS, RR, XS)                                                                                      \
     do {                                                                                                                         \
-        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k_eq_bwd_bf<NB, SS, RR>),                        \
+        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k_eq_bwd_bf<NB, SS, RR, XS>),                    \
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)               \
             return V2VAE_ELAUNCH;                                                                                                \
-        hipLaunchKernelGGL((k_eq_bwd_bf<NB, SS, RR>), dim3(l.nblk_eq), dim3(NT), lds, st, l, y, gx, ws);                          \
+        hipLaunchKernelGGL((k_eq_bwd_bf<NB, SS, RR, XS>), dim3(l.nblk_eq), dim3(NT), lds, st, l, y, gx, ws);                      \
     } while (0)
-#define V2VAE_LAUNCH_EQBF(NB)                                                \
+#define V2VAE_LAUNCH_EQBF(NB, XS)                                            \
     do {                                                                     \
-        if (l.S == 1) { if (l.ns == 1) V2VAE_LAUNCH_EQBF_R(NB, 1, true); else V2VAE_LAUNCH_EQBF_R(NB, 1, false); } \
-        else { if (l.ns == 1) V2VAE_LAUNCH_EQBF_R(NB, 2, true); else V2VAE_LAUNCH_EQBF_R(NB, 2, false); }          \
+        if (l.S == 1) { if (l.ns == 1) V2VAE_LAUNCH_EQBF_R(NB, 1, true, XS); else V2VAE_LAUNCH_EQBF_R(NB, 1, false, XS); } \
+        else { if (l.ns == 1) V2VAE_LAUNCH_EQBF_R(NB, 2, true, XS); else V2VAE_LAUNCH_EQBF_R(NB, 2, false, XS); }          \
     } while (0)
+#define V2VAE_LAUNCH_EQBF_X(NB)                                  \
+    do {   /* (complex model only) */                            \
+        if (l.S == 1) V2VAE_LAUNCH_EQBF_R(NB, 1, false, 1);      \
+        else V2VAE_LAUNCH_EQBF_R(NB, 2, false, 1);               \
+    } while (0)
+        if (l.eqbf_xs == 1) {   // 16 k + 1 lags: k blocks, the last lag and the column of ones on the side (at 81 the sixth block stays)
+            switch (l.eqbf_nb) {
+                case 1: V2VAE_LAUNCH_EQBF_X(1); break;
+                case 2: V2VAE_LAUNCH_EQBF_X(2); break;
+                case 3: V2VAE_LAUNCH_EQBF_X(3); break;
+                case 4: V2VAE_LAUNCH_EQBF_X(4); break;
+                default: return V2VAE_ESIZE;
+            }
+            return V2VAE_OK;
+        }
         switch (l.eqb16) {
-            case 1: V2VAE_LAUNCH_EQBF(1); break;
-            case 2: V2VAE_LAUNCH_EQBF(2); break;
-            case 3: V2VAE_LAUNCH_EQBF(3); break;
-            case 4: V2VAE_LAUNCH_EQBF(4); break;
-            case 5: V2VAE_LAUNCH_EQBF(5); break;
-            case 6: V2VAE_LAUNCH_EQBF(6); break;
+            case 1: V2VAE_LAUNCH_EQBF(1, -1); break;
+            case 2: V2VAE_LAUNCH_EQBF(2, -1); break;
+            case 3: V2VAE_LAUNCH_EQBF(3, -1); break;
+            case 4: V2VAE_LAUNCH_EQBF(4, -1); break;
+            case 5: V2VAE_LAUNCH_EQBF(5, -1); break;
+            case 6: V2VAE_LAUNCH_EQBF(6, -1); break;
             default: return V2VAE_ESIZE;
         }
+#undef V2VAE_LAUNCH_EQBF_X
 #undef V2VAE_LAUNCH_EQBF
 #undef V2VAE_LAUNCH_EQBF_R
         return V2VAE_OK;

@@ -214,6 +214,9 @@ int make_layout(const v2vae_problem* p, Lay* out) {
         l.eqb16 = (l.l2 + 1 + 15) / 16;
     l.eqb16_rec = 2 * (16 * l.eqb16) * (16 * l.eqb16);
     l.eqbf = (l.eqb16 && eqbf_ok) ? 1 : 0;
+    // (16 k + 1 lags: the last block would hold one lag and the column of ones alone; they go on the side)
+    l.eqbf_xs = (l.eqbf && l.ns == 2 && l.l2 > 16 && l.l2 % 16 == 1 && l.l2 != 81) ? 1 : -1;   // (complex model; 81 lags: registers)
+    l.eqbf_nb = l.eqbf_xs >= 0 ? l.l2 / 16 : l.eqb16;
     {
         // sample tile (interleaved pairs), per-symbol gradient combinations (5 per symbol), constant ones / zeros (64 S each); afterwards the record
         int64_t a = (((int64_t)2 * l.tile_len + 3) & ~(int64_t)3) + 5 * EQ_TB + 128 * l.S;
@@ -224,7 +227,8 @@ int make_layout(const v2vae_problem* p, Lay* out) {
     }
     if (l.eqb16) {
         // (the bf16 instance with three lag blocks holds three workgroups per CU)
-        const int res = 256 * (l.eqb16 <= 2 ? 4 : l.eqb16 == 3 ? (l.eqbf ? 3 : 4) : 2);
+        const int nbm = l.eqbf ? l.eqbf_nb : l.eqb16;   // blocks whose accumulators the instance holds
+        const int res = 256 * (l.eqbf_xs == 1 ? (nbm <= 2 ? 3 : 2) : nbm <= 2 ? 4 : nbm == 3 ? (l.eqbf ? 3 : 4) : 2);
         l.nblk_eq = l.ntile_eq < res ? l.ntile_eq : res;
     }
     else if (l.use_eqcxb && l.eqcxb_nbl >= 3) l.nblk_eq = l.ntile_eq < 256 ? l.ntile_eq : 256;

@@ -96,6 +96,8 @@ struct Lay {
     // backward of the complex equaliser on 16-lag blocks (k_eq_bwd_cx<NB16>): eqb16 = number of blocks (0: not used; l2 <= 79),
     // records [2 planes][16 eqb16][16 eqb16] at o_part_eqcx / o_tot_eqcx
     int eqb16, eqb16_rec, lds_eqb16;
+    int eqbf_nb, eqbf_xs;    // bf16 instance: lag blocks on the matrix pipe, and -1 (all of them) / 1 (16 eqbf_nb + 1 lags: the last lag and
+                             // the column of ones on the side); the record keeps eqb16 blocks
     int eqbf;                // 1: its instance on the bf16 matrix pipe in split arithmetic (k_eq_bwd_bf: one or two samples per symbol)
     int64_t o_part_eqcx, o_tot_eqcx;
     // blocked matrix-core equaliser path (complex, 31 < l2 <= 95): lag rows in blocks of 32
