@@ -483,6 +483,10 @@ __host__ __device__ constexpr int cx3_wt(int S, bool BFX) { return S <= 2 ? (BFX
 // staged symbols per strip (16 used beyond the windows; 32 keeps the gradient update of a slab, 64 lanes wide, inside the arrays)
 __host__ __device__ constexpr int cx3_ms(int S, bool BFX) { return cx3_wt(S, BFX) + 32; }
 constexpr int CX3_NW = 8;                   // waves per workgroup
+#ifndef V2VAE_CX3_BFK
+#define V2VAE_CX3_BFK 1
+#endif
+constexpr bool CX3_BFK = V2VAE_CX3_BFK != 0;   // (with the split-bf16 products) dE/dH on the bf16 matrix pipe as well
 constexpr int CX3_ADB = 16 * 32 + 4;        // 4-vectors of the anti-diagonal buffer (two planes of 8 tap-pair rows of 32 windows, a zero vector behind each)
 // floats of one wave's private LDS: 7 moment planes, the per-symbol gradient 4-vectors, the anti-diagonal buffer (which the
 // transposing buffer of the rho / sigma rows shares: the two are used one after the other within a slab), and with BFX the
@@ -959,6 +963,53 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_sched_barrier(0);
+            if (BFX && CX3_BFK) {
+                // dE/dH on the bf16 matrix pipe too (v_mfma_f32_16x16x32_bf16: the slab's 32 windows are ONE k-step; lane
+                // (tap i16, group kq) carries windows 8 kq .. 8 kq + 7): Re += rho^T mu_a + sigma^T mu_b, Im += sigma^T mu_a - rho^T mu_b
+                // (K1 holds Re, K2 Im).  rho / sigma are split in registers; the means are the bf16 planes of the H X product.
+                float ar[8], as[8];
+#pragma unroll
+                for (int st = 0; st < 8; ++st) { ar[st] = Tr[(8 * kq + st) * 17 + i16]; as[st] = Ts[(8 * kq + st) * 17 + i16]; }
+                u32x4 rho[3], sig[3], nrho[3];
+#pragma unroll
+                for (int k2 = 0; k2 < 4; ++k2) {
+                    unsigned pr[2][3], ps[2][3];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        bf16_split3_trunc(ar[2 * k2 + u], &pr[u][0], &pr[u][1], &pr[u][2]);
+                        bf16_split3_trunc(as[2 * k2 + u], &ps[u][0], &ps[u][1], &ps[u][2]);
+                    }
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) {
+                        rho[pc][k2] = __builtin_amdgcn_perm(pr[1][pc], pr[0][pc], 0x07060302u);
+                        sig[pc][k2] = __builtin_amdgcn_perm(ps[1][pc], ps[0][pc], 0x07060302u);
+                        nrho[pc][k2] = rho[pc][k2] ^ 0x80008000u;
+                    }
+                }
+                typedef const unsigned __attribute__((address_space(3))) * lword_p;
+                lword_p xw = (lword_p)(reinterpret_cast<const unsigned*>(Xb) + ((tsl + 8 * kq + i16) >> 1));
+                asm volatile("" : "+v"(xw));
+                const unsigned shk = (i16 & 1) * 16;
+#pragma unroll
+                for (int dp = 2; dp >= 0; --dp) {   // the small pieces first
+                    u32x4 ya, yb;
+                    unsigned wa[5], wb[5];
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) { wa[q] = xw[dp * (MS / 2) + q]; wb[q] = xw[(3 + dp) * (MS / 2) + q]; }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        ya[q] = __builtin_amdgcn_alignbit(wa[q + 1], wa[q], shk);
+                        yb[q] = __builtin_amdgcn_alignbit(wb[q + 1], wb[q], shk);
+                    }
+#pragma unroll
+                    for (int tp = 2 - dp; tp >= 0; --tp) {
+                        K1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bfx8, rho[tp]), __builtin_bit_cast(bfx8, ya), K1, 0, 0, 0);
+                        K2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bfx8, sig[tp]), __builtin_bit_cast(bfx8, ya), K2, 0, 0, 0);
+                        K1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bfx8, sig[tp]), __builtin_bit_cast(bfx8, yb), K1, 0, 0, 0);
+                        K2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bfx8, nrho[tp]), __builtin_bit_cast(bfx8, yb), K2, 0, 0, 0);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 const int w = 4 * s + kq;   // window of this lane's k-slot; tap i16
@@ -979,6 +1030,7 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
                 __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            }
             }
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_wave_barrier();
@@ -1018,7 +1070,7 @@ __global__ __launch_bounds__(CX3_NW * 64) void k_elbo_cx3(Lay l, const float* __
         }
         vsum[q][0] = v0; vsum[q][1] = v1; vsum[q][2] = v2; vsum[q][3] = v3;
     }
-    const f32x4 Re = K1 - K3, Im = K1 + K2;
+    const f32x4 Re = (BFX && CX3_BFK) ? K1 : K1 - K3, Im = (BFX && CX3_BFK) ? K2 : K1 + K2;
     for (int w = 0; w < NWP; ++w) {
         if (wsub == w) {
 #pragma unroll
