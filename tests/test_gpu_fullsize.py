@@ -126,7 +126,14 @@ def test_matrix_core_kernels_agree_with_the_generic_kernels_at_the_headline_size
         assert e < 1e-5, (name, e)
 
 
-@pytest.mark.parametrize("shape", [HEADLINE, LONG_CHANNEL])
+# further kernel instances at 2^18 symbols: 17 taps per phase (blocked ELBO kernel, one block and a tap on the side, two waves per
+# SIMD), one sample per symbol with 49 lags (three lag blocks and a lag on the side), four samples per symbol, 33 / 81 lags
+# (two blocks and a lag on the side / six blocks), 47-tap channel with three tap blocks
+OTHER_INSTANCES = [(33, 2, 33, 33, 4, 18), (25, 1, 49, 49, 4, 18), (9, 4, 25, 25, 4, 18), (65, 2, 81, 81, 4, 17), (95, 2, 17, 17, 4, 17),
+                   (41, 1, 65, 65, 8, 17)]
+
+
+@pytest.mark.parametrize("shape", [HEADLINE, LONG_CHANNEL] + OTHER_INSTANCES)
 def test_full_size_step_is_bitwise_reproducible(shape):
     """Every sum of the path has a fixed order (per-workgroup records, two-stage record sums, no floating-point atomics): the
     same inputs give the same bits, on a fresh workspace and on one that has been used."""
