@@ -311,8 +311,10 @@ def main():
                 traffic = next(v for k, v in tr.items() if "k_elbo_cx" in k)
         except Exception:
             traffic = None
-        # how busy the one fp32 pipe of a SIMD was in the dominant kernel: (matrix cycles + 4 x vector instructions) / elapsed
-        # cycles, from the committed SQ counter passes of the same command (tools/profile_step.sh, tools/pipe_bound.py)
+        # how busy a SIMD's two pipes were in the dominant kernel: (matrix cycles + vector cycles) / elapsed cycles, from the
+        # committed SQ counter passes of the same command (tools/profile_step.sh, tools/pipe_bound.py).  With f32 matrix
+        # instructions the two shared one issue slot and the sum was a bound; the bf16 ones of the split arithmetic run beside
+        # the vector instructions, so the sum can exceed 1 (it does in the equaliser backward)
         pipe = None
         try:
             with open(os.path.join(ROOT, "profiles", "latest_pipe.json")) as fh:
