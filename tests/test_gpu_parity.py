@@ -322,7 +322,8 @@ def test_complex_L65_shape_matches_oracle():
 
 
 @pytest.mark.parametrize("l1,l2,S,B", [(33, 33, 2, 700), (33, 33, 1, 333), (9, 47, 1, 300), (49, 49, 2, 450), (63, 63, 2, 520),
-                                       (65, 65, 2, 1100), (65, 65, 1, 300), (81, 81, 1, 270), (31, 95, 2, 600), (95, 95, 1, 257)])
+                                       (65, 65, 2, 1100), (65, 65, 1, 300), (81, 81, 1, 270), (31, 95, 2, 600), (95, 95, 1, 257),
+                                       (9, 33, 1, 400), (25, 65, 2, 500), (17, 49, 2, 300)])
 def test_complex_long_equaliser_blocked_kernel_matches_oracle(l1, l2, S, B):
     """31 < second-order lags <= 95: the equaliser kernels on the bf16 matrix pipe in split arithmetic (forward: 3 ... 6 blocks of
     16 lags, backward likewise; lag counts of the form 16 k + 1, whose last lag the forward carries on the side of k blocks;
