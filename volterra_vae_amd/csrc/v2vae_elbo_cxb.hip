@@ -29,7 +29,9 @@
 
 namespace v2vae {
 
-
+#ifndef CXB_HOLDB
+#define CXB_HOLDB 1
+#endif
 // compact tap k of phase r -> channel tap index or -1
 __device__ __forceinline__ int cxb_tap(const Lay& l, int r, int k) {
     if (k >= l.LE) return -1;
@@ -287,10 +289,15 @@ __global__ __launch_bounds__(cxb_nw(NB, XT) * 64) void k_elbo_cxb(Lay l, const f
             f2 a0v = 0.f, a1v = 0.f, q0v = 0.f, q1v = 0.f, sd0v = 0.f, sd1v = 0.f, vsv = 0.f;
             // the A operands of block pair p + 1 are requested before the MFMA chain of pair p is issued; sched_barrier keeps
             // the compiler from hoisting more than that one pair of loads (register budget)
-            u32x4 abuf[2][6];    // two register sets, alternating by block pair: no copies; [piece][chunk] images of 16 bytes per lane
+            // block pairs the table fragments are requested ahead of their use: the chains wait for these loads (L2) more than for
+            // anything else; two pairs ahead where the registers reach (two tap blocks: 6.08 -> 5.97 ms; three ahead: 6.10)
+            constexpr int PFD = NB == 2 ? 2 : 1;
+            u32x4 abuf[PFD + 1][6];    // register sets rotating by block pair: no copies; [piece][chunk] images of 16 bytes per lane
             typedef const u32x4 __attribute__((address_space(1))) * gvec_p;
 #pragma unroll
-            for (int s = 0; s < 6; ++s) abuf[0][s] = ((gvec_p)Abase)[s * 64 + ulane];
+            for (int q = 0; q < PFD && q < NB * NB; ++q)
+#pragma unroll
+                for (int s = 0; s < 6; ++s) abuf[q][s] = ((gvec_p)(Abase + (size_t)q * CXB_STEPS * 64))[s * 64 + ulane];
             // B operands: k-slot (chunk c, lane half h, element j) = (stream c, tap 8 h + j of block jb), i.e. eight consecutive bf16
             // of stream c from staged symbol tsl + i + 16 jb + 8 h on: five aligned words, an odd window shifts by one piece
             typedef const unsigned __attribute__((address_space(3))) * lword_p;
@@ -306,6 +313,27 @@ __global__ __launch_bounds__(cxb_nw(NB, XT) * 64) void k_elbo_cxb(Lay l, const f
                     xbufB[xb] = Xbase[(xb * 2 + 1) * 64 + ulane];
                 }
             }
+            // the B operand of a tap block serves every output block: with two blocks both are formed once per slab and held
+            auto load_b = [&](int jb, u32x4 (&d)[3][2]) {
+                lword_p xw = (lword_p)(reinterpret_cast<const unsigned*>(s_xb) + ((tsl + i + 16 * jb + 8 * h) >> 1));
+                asm volatile("" : "+v"(xw));
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) {
+                        unsigned w[5];
+#pragma unroll
+                        for (int q = 0; q < 5; ++q) w[q] = xw[(c * 3 + pc) * (MS / 2) + q];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) d[pc][c][q] = __builtin_amdgcn_alignbit(w[q + 1], w[q], sh);
+                    }
+            };
+            constexpr bool HOLDB = CXB_HOLDB && NB == 2;
+            u32x4 bd[HOLDB ? NB : 1][3][2];
+            if (HOLDB) {
+#pragma unroll
+                for (int jb = 0; jb < NB; ++jb) load_b(jb, bd[jb]);
+            }
 #pragma unroll
             for (int xb = 0; xb < NB; ++xb) {
                 f32x16 U;
@@ -315,33 +343,23 @@ __global__ __launch_bounds__(cxb_nw(NB, XT) * 64) void k_elbo_cxb(Lay l, const f
                 for (int jb = 0; jb < NB; ++jb) {
                     const int pr = xb * NB + jb;
                     __builtin_amdgcn_sched_barrier(0);
-                    if (pr + 1 < NB * NB) {
-                        const gvec_p A = (gvec_p)(Abase + (size_t)(pr + 1) * CXB_STEPS * 64);
+                    if (pr + PFD < NB * NB) {
+                        const gvec_p A = (gvec_p)(Abase + (size_t)(pr + PFD) * CXB_STEPS * 64);
 #pragma unroll
-                        for (int s = 0; s < 6; ++s) abuf[(pr + 1) & 1][s] = A[s * 64 + ulane];
+                        for (int s = 0; s < 6; ++s) abuf[(pr + PFD) % (PFD + 1)][s] = A[s * 64 + ulane];
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     {
-                        lword_p xw = (lword_p)(reinterpret_cast<const unsigned*>(s_xb) + ((tsl + i + 16 * jb + 8 * h) >> 1));
-                        asm volatile("" : "+v"(xw));
-                        u32x4 d[3][2];
-#pragma unroll
-                        for (int c = 0; c < 2; ++c)
-#pragma unroll
-                            for (int pc = 0; pc < 3; ++pc) {
-                                unsigned w[5];
-#pragma unroll
-                                for (int q = 0; q < 5; ++q) w[q] = xw[(c * 3 + pc) * (MS / 2) + q];
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) d[pc][c][q] = __builtin_amdgcn_alignbit(w[q + 1], w[q], sh);
-                            }
+                        u32x4 dl[3][2];
+                        if (!HOLDB) load_b(jb, dl);
+                        const u32x4 (&d)[3][2] = HOLDB ? bd[jb] : dl;
                         // table piece x operand piece, smallest products first: (1,3) (2,2) (3,1) (1,2) (2,1) (1,1)
                         constexpr int TP6[6] = {0, 1, 2, 0, 1, 0}, DP6[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
                         for (int k = 0; k < 6; ++k)
 #pragma unroll
                             for (int c = 0; c < 2; ++c)
-                                U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bfx8, abuf[pr & 1][TP6[k] * 2 + c]),
+                                U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bfx8, abuf[pr % (PFD + 1)][TP6[k] * 2 + c]),
                                                                             __builtin_bit_cast(bfx8, d[DP6[k]][c]), U, 0, 0, 0);
                     }
                     // (no (H.H) s product: the term of E that holds it and its variance gradient come from k_g2_cx)
@@ -459,9 +477,11 @@ __global__ __launch_bounds__(cxb_nw(NB, XT) * 64) void k_elbo_cxb(Lay l, const f
             }
 
             // ---- pass B: per output block H w, the anti-diagonal sums of the moment gradients, dE/dH
-            u32x4 hbuf[2][6];
+            u32x4 hbuf[PFD + 1][6];
 #pragma unroll
-            for (int s = 0; s < 6; ++s) hbuf[0][s] = ((gvec_p)Abase)[(6 + s) * 64 + ulane];
+            for (int q = 0; q < PFD && q < NB * NB; ++q)
+#pragma unroll
+                for (int s = 0; s < 6; ++s) hbuf[q][s] = ((gvec_p)(Abase + (size_t)q * CXB_STEPS * 64))[(6 + s) * 64 + ulane];
             // B operands of H w: (alpha, beta) of the lane's eight taps of block jb in three bf16 pieces each (plain vector
             // instructions: they run beside the matrix pipe), chunk 0 = alpha, chunk 1 = beta.  Up to two blocks they are formed
             // once per slab; with three the registers do not reach and every output block forms them again.
@@ -495,10 +515,10 @@ __global__ __launch_bounds__(cxb_nw(NB, XT) * 64) void k_elbo_cxb(Lay l, const f
                 for (int jb = 0; jb < NB; ++jb) {
                     const int pr = xb * NB + jb;
                     __builtin_amdgcn_sched_barrier(0);
-                    if (pr + 1 < NB * NB) {
-                        const gvec_p A = (gvec_p)(Abase + (size_t)(pr + 1) * CXB_STEPS * 64);
+                    if (pr + PFD < NB * NB) {
+                        const gvec_p A = (gvec_p)(Abase + (size_t)(pr + PFD) * CXB_STEPS * 64);
 #pragma unroll
-                        for (int s = 0; s < 6; ++s) hbuf[(pr + 1) & 1][s] = A[(6 + s) * 64 + ulane];
+                        for (int s = 0; s < 6; ++s) hbuf[(pr + PFD) % (PFD + 1)][s] = A[(6 + s) * 64 + ulane];
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     {
@@ -509,7 +529,7 @@ __global__ __launch_bounds__(cxb_nw(NB, XT) * 64) void k_elbo_cxb(Lay l, const f
                         for (int k = 0; k < 6; ++k)
 #pragma unroll
                             for (int c = 0; c < 2; ++c)
-                                HW = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bfx8, hbuf[pr & 1][TP6[k] * 2 + c]),
+                                HW = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bfx8, hbuf[pr % (PFD + 1)][TP6[k] * 2 + c]),
                                                                              __builtin_bit_cast(bfx8, d[DP6[k]][c]), HW, 0, 0, 0);
                     }
                 }
