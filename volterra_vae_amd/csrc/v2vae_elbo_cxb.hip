@@ -147,7 +147,12 @@ __global__ __launch_bounds__(cxb_nw(NB, XT) * 64) void k_elbo_cxb(Lay l, const f
     // dE/dH block (xb, jb) = sum over windows of (rho + i sigma)^T conj(X), a complex 16x16 accumulation, from three real products
     // instead of four:  K1 = (rho + sigma)^T mu_a,  K2 = -rho^T (mu_a + mu_b),  K3 = sigma^T (mu_a - mu_b);  Re = K1 - K3,
     // Im = K1 + K2 (combined once at the end: the sums are linear)
-    f32x4 K1[NB][NB], K2[NB][NB], K3[NB][NB];
+    // BFK (the two-wave instance): the same accumulation on the bf16 matrix pipe in split arithmetic (v_mfma_f32_16x16x32_bf16,
+    // the slab's 32 windows one k-step): Re += rho^T mu_a + sigma^T mu_b, Im += sigma^T mu_a - rho^T mu_b, rho / sigma split in
+    // registers, the means read from the bf16 planes of the H X product - an f32 matrix instruction holds the vector issue of
+    // the SIMD's other wave.  K1 holds Re and K2 Im then, K3 is not used.
+    constexpr bool BFK = cxb_bfk(NB, XT);
+    f32x4 K1[NB][NB], K2[NB][NB], K3[BFK ? 1 : NB][BFK ? 1 : NB];
     // vector gradients (d/dh1 Re, Im; d/d diag H Re, Im), accumulated in the TRANSPOSED layout the 16x16 MFMAs read (lane = (tap
     // lane & 15, window group lane >> 4)): one register per block and quantity instead of eight in the window-on-lane layout
     float vacc[NB][4];
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(cxb_nw(NB, XT) * 64) void k_elbo_cxb(Lay l, const f
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) { K1[a][b][g] = 0.f; K2[a][b][g] = 0.f; K3[a][b][g] = 0.f; }
+            for (int g = 0; g < 4; ++g) { K1[a][b][g] = 0.f; K2[a][b][g] = 0.f; if (!BFK) K3[a][b][g] = 0.f; }
 #pragma unroll
         for (int q = 0; q < 4; ++q) vacc[a][q] = 0.f;
     }
@@ -628,15 +633,18 @@ __global__ __launch_bounds__(cxb_nw(NB, XT) * 64) void k_elbo_cxb(Lay l, const f
                 __builtin_amdgcn_sched_barrier(0);
                 {
                     const int xa = lane & 15, kq = lane >> 4;
+                    // this lane's eight windows of the slab: 4 st + kq on the f32 matrix instructions (four windows per k-step),
+                    // 8 kq + st on the bf16 ones (32 windows per instruction, eight consecutive ones per lane group)
+                    auto win = [&](int st) { return BFK ? 8 * kq + st : 4 * st + kq; };
                     float ar[8], as[8];
 #pragma unroll
                     for (int st = 0; st < 8; ++st) {
-                        ar[st] = Tb[(4 * st + kq) * TP + xa];
-                        as[st] = Tb[(4 * st + kq) * TP + 16 + xa];
+                        ar[st] = Tb[win(st) * TP + xa];
+                        as[st] = Tb[win(st) * TP + 16 + xa];
                     }
 #pragma unroll
                     for (int st = 0; st < 8; ++st) {
-                        const float* tv = Tv + (4 * st + kq) * TVP + xa;
+                        const float* tv = Tv + win(st) * TVP + xa;
                         vacc[xb][0] += tv[0];
                         vacc[xb][1] += tv[16];
                         vacc[xb][2] += tv[32];
@@ -645,11 +653,65 @@ __global__ __launch_bounds__(cxb_nw(NB, XT) * 64) void k_elbo_cxb(Lay l, const f
                     if (XT) {   // column e of dE/dH: this lane's share of sum_w (rho, sigma)(w, x) mu(w + e)
 #pragma unroll
                         for (int st = 0; st < 8; ++st) {
-                            const int w = tsl + 4 * st + kq + EX;
+                            const int w = tsl + win(st) + EX;
                             const f2 me = {s_mu[w], s_mu[MS + w]};
                             col[xb] += ar[st] * f2{me.x, -me.y} + as[st] * f2{me.y, me.x};
                         }
                     }
+                    if (BFK) {
+                        u32x4 rho[3], sig[3], nrho[3];
+#pragma unroll
+                        for (int k2 = 0; k2 < 4; ++k2) {
+                            unsigned pr[2][3], ps[2][3];
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                bf16_split3_trunc(ar[2 * k2 + u], &pr[u][0], &pr[u][1], &pr[u][2]);
+                                bf16_split3_trunc(as[2 * k2 + u], &ps[u][0], &ps[u][1], &ps[u][2]);
+                            }
+#pragma unroll
+                            for (int pc = 0; pc < 3; ++pc) {
+                                rho[pc][k2] = __builtin_amdgcn_perm(pr[1][pc], pr[0][pc], 0x07060302u);
+                                sig[pc][k2] = __builtin_amdgcn_perm(ps[1][pc], ps[0][pc], 0x07060302u);
+                                nrho[pc][k2] = rho[pc][k2] ^ 0x80008000u;
+                            }
+                        }
+#pragma unroll
+                        for (int jb = 0; jb < NB; ++jb) {
+                            // B operands: the means of windows 8 kq .. 8 kq + 7 at tap 16 jb + xa: eight consecutive bf16 of either
+                            // stream from staged symbol tsl + 8 kq + 16 jb + xa on (five aligned words; an odd tap shifts by one piece)
+                            lword_p xw = (lword_p)(reinterpret_cast<const unsigned*>(s_xb) + ((tsl + 8 * kq + 16 * jb + xa) >> 1));
+                            asm volatile("" : "+v"(xw));
+                            const unsigned shk = (xa & 1) * 16;
+#pragma unroll
+                            for (int dp = 2; dp >= 0; --dp) {   // the small pieces first
+                                u32x4 ya, yb;
+                                unsigned wa[5], wb[5];
+#pragma unroll
+                                for (int q = 0; q < 5; ++q) { wa[q] = xw[dp * (MS / 2) + q]; wb[q] = xw[(3 + dp) * (MS / 2) + q]; }
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    ya[q] = __builtin_amdgcn_alignbit(wa[q + 1], wa[q], shk);
+                                    yb[q] = __builtin_amdgcn_alignbit(wb[q + 1], wb[q], shk);
+                                }
+#pragma unroll
+                                for (int tp = 2 - dp; tp >= 0; --tp) {
+                                    K1[xb][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bfx8, rho[tp]), __builtin_bit_cast(bfx8, ya), K1[xb][jb], 0, 0, 0);
+                                    K2[xb][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bfx8, sig[tp]), __builtin_bit_cast(bfx8, ya), K2[xb][jb], 0, 0, 0);
+                                    K1[xb][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bfx8, sig[tp]), __builtin_bit_cast(bfx8, yb), K1[xb][jb], 0, 0, 0);
+                                    K2[xb][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bfx8, nrho[tp]), __builtin_bit_cast(bfx8, yb), K2[xb][jb], 0, 0, 0);
+                                }
+                            }
+                            if (XT && xb == 0) {   // row e of dE/dH, once per slab: sum_w (rho, sigma)(w, e) mu(w + j)
+#pragma unroll
+                                for (int st = 0; st < 8; ++st) {
+                                    const int w = tsl + win(st) + 16 * jb + xa;
+                                    const float ma = s_mu[w], mb = s_mu[MS + w];
+                                    const f2 rs = ld2(Tb + win(st) * TP + 32);   // (rho, sigma) of tap e at this window
+                                    row[jb] += ma * rs + mb * f2{rs.y, -rs.x};
+                                }
+                            }
+                        }
+                    } else {
 #pragma unroll
                     for (int jb = 0; jb < NB; ++jb) {
         #pragma unroll
@@ -673,6 +735,7 @@ __global__ __launch_bounds__(cxb_nw(NB, XT) * 64) void k_elbo_cxb(Lay l, const f
                         __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
                         __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
                         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                    }
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -728,8 +791,8 @@ __global__ __launch_bounds__(cxb_nw(NB, XT) * 64) void k_elbo_cxb(Lay l, const f
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int a = 16 * xb + 4 * (lane >> 4) + g, b = 16 * jb + (lane & 15);
-                        img[a * LEB + b] += K1[xb][jb][g] - K3[xb][jb][g];
-                        img[(LEB + a) * LEB + b] += K1[xb][jb][g] + K2[xb][jb][g];
+                        img[a * LEB + b] += BFK ? K1[xb][jb][g] : K1[xb][jb][g] - K3[xb][jb][g];
+                        img[(LEB + a) * LEB + b] += BFK ? K2[xb][jb][g] : K1[xb][jb][g] + K2[xb][jb][g];
                     }
                 {
                     float v0 = vacc[xb][0], v1 = vacc[xb][1], v2 = vacc[xb][2], v3 = vacc[xb][3];

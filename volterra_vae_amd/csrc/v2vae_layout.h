@@ -36,6 +36,9 @@ constexpr int CX_BLOCKS = 256;       // one workgroup per CU (the LDS image take
 // the 512-register budget of one wave per SIMD: four waves on 512-window tiles.
 __host__ __device__ constexpr int cxb_nw(int nbk, int xt) { return (nbk == 1 && xt) ? 8 : 4; }
 __host__ __device__ constexpr int cxb_twb(int nbk, int xt) { return (nbk == 1 && xt) ? 256 : 512; }
+// the instance of the blocked ELBO kernel that accumulates dE/dH on the bf16 matrix pipe in split arithmetic: the one at two
+// waves per SIMD (with one wave there is no second wave whose vector issue an f32 matrix instruction would hold up: no gain)
+__host__ __device__ constexpr bool cxb_bfk(int nbk, int xt) { return nbk == 1 && xt; }
 constexpr int CXB_STEPS = 48;        // 256-byte rows of one block pair's constant operand image: the bf16 images of the H X and
                                      // H w tables, [2 tables][3 pieces][2 chunks][64 lanes][8 bf16]
 constexpr int CXB_TPX = 35;          // row pitch of its transposing buffer when an extra tap rides along (columns 32, 33)
